@@ -1,0 +1,134 @@
+/*
+ * venc_hip.h -- thin C-ABI of the MI355X (gfx950) macroblock-loop engine.
+ *
+ * This is the device-facing half of the drop-in boundary.  The reference's only
+ * entry into video coding is x264_encoder_encode() (av_encode.c:970, flush twin
+ * av_encode.c:1078) plus open/close (av_encode.c:408, :443); include/x264.h
+ * re-declares exactly that surface and csrc/x264_shim.c implements it in C on
+ * top of the functions below ("host code stays in C and calls HIP through a
+ * thin C-ABI").  Plain pointers and sizes only; no C++ or torch types.
+ *
+ * Model: an encoder context owns
+ *   - an input pool of I420 frame slots in HBM (display size, tight planes), or
+ *     borrows a caller-provided device buffer of the same layout;
+ *   - up to max_items independent prediction chains ("items": streams or closed
+ *     GOPs) that advance in lock-step, one frame per step;
+ *   - an output pool in pinned host memory that the pack kernel writes directly.
+ * One venc_encode_step() launches, on the context's HIP stream,
+ *   P step: k_me -> k_inter -> k_cavlc -> k_scan -> k_pack
+ *   I step: k_intra      -> k_cavlc -> k_scan -> k_pack
+ * for all items at once (grid z = item).  Nothing blocks until venc_wait().
+ *
+ * All functions return 0 on success, a negative value on error (never abort,
+ * never print unless VENC_DEBUG is set) -- the reference's convention for the
+ * encoder (av_encode.c:971-974).
+ */
+#ifndef VENC_HIP_H
+#define VENC_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VENC_ABI_VERSION 1
+#define VENC_MAX_ITEMS 64
+
+typedef struct venc_ctx venc_ctx;
+
+typedef struct {
+    int width, height; /* display size, both even */
+    int qp;            /* fixed QP 12..51 */
+    int n_slices;      /* MB-row bands per frame (clamped to 1..mb_height, <= 256) */
+    int max_items;     /* independent chains advanced per step, 1..VENC_MAX_ITEMS */
+    int in_slots;      /* input pool size in frames (0: caller will use venc_set_input) */
+    int out_slots;     /* output pool size in frames */
+    int device;        /* HIP device ordinal */
+} venc_config;
+
+/* Per-slice record of an encoded frame (raw RBSP: slice header + slice data +
+ * trailing bits, no NAL header, no emulation prevention, no length prefix). */
+typedef struct {
+    uint32_t byte_off; /* offset inside data */
+    uint32_t nbytes;
+    uint32_t nbits;
+    uint32_t pad;
+} venc_slice;
+
+typedef struct {
+    const uint8_t *data;      /* pinned host memory, valid until the slot is reused */
+    const venc_slice *slices; /* n_slices entries */
+    uint32_t n_slices;
+    uint32_t total_bytes;
+    uint32_t error;
+} venc_frame;
+
+int venc_abi_version(void);
+const char *venc_last_error(void);
+int venc_device_count(void);
+
+int venc_open(const venc_config *cfg, venc_ctx **out);
+void venc_close(venc_ctx *c);
+
+/* geometry */
+int venc_mb_width(const venc_ctx *c);
+int venc_mb_height(const venc_ctx *c);
+int venc_n_slices(const venc_ctx *c);
+size_t venc_frame_bytes(const venc_ctx *c); /* w*h*3/2: size of one input slot */
+
+/* Input.  venc_upload copies host planes into pool slot `slot` (async on the
+ * copy stream); the source may be reused once venc_upload_sync() returns.
+ * venc_set_input borrows caller-owned device memory laid out as consecutive
+ * I420 frames (frame_stride bytes apart) instead of the internal pool. */
+int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int stride_y, const uint8_t *u, int stride_u,
+                const uint8_t *v, int stride_v);
+int venc_upload_sync(venc_ctx *c);
+int venc_set_input(venc_ctx *c, const void *d_frames, size_t frame_stride, int n_frames);
+void *venc_input_slot_ptr(venc_ctx *c, int slot); /* device pointer of an internal pool slot */
+/* pinned host allocation helpers used by x264_picture_alloc (av_encode.c:415) */
+void *venc_host_alloc(size_t bytes);
+void venc_host_free(void *p);
+
+/* One lock-step frame for n_items chains.  in_slots[i] / out_slots[i]: input
+ * frame slot and output slot of item i.  is_idr: all items code an IDR picture
+ * (no reference), else a P picture predicted from the item's previous
+ * reconstruction.  idr_ids[i]: idr_pic_id (used when is_idr). */
+int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, const int *out_slots, int is_idr,
+                     int frame_num, const int *idr_ids);
+
+/* Completion tracking: venc_mark() records an event after everything enqueued
+ * so far; venc_wait(ticket) blocks the host until that point. */
+int venc_mark(venc_ctx *c);
+int venc_wait(venc_ctx *c, int ticket);
+int venc_sync(venc_ctx *c);
+
+/* Output of out slot `slot` (valid after the producing step completed). */
+int venc_get_frame(venc_ctx *c, int slot, venc_frame *out);
+
+/* Introspection for kernel-level parity tests: copies device intermediates of
+ * chain `item` (state after the last step) to host memory.
+ *   what 0: mvsad   u32[nmb]      sad<<16 | (dy&255)<<8 | (dx&255)
+ *        1: levels  i16[nmb][27][16]
+ *        2: mbinfo  u8[nmb][32]   nnz[24], cbp, flags, pad
+ *        3: mbnbits u32[nmb]
+ *        4/5/6: reconstructed Y/U/V plane (coded size) of the last step
+ *        7: mboff   u32[nmb]
+ * Level record per macroblock (27 blocks x 16 levels, scan order):
+ *   0..15 luma 4x4 blocks in luma4x4BlkIdx order; 16 Intra16x16 luma DC;
+ *   17/18 Cb/Cr DC (4 levels); 19..22 Cb AC; 23..26 Cr AC (levels at 1..15). */
+int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_t dst_bytes);
+
+/* Stand-alone launchers used by micro-benchmarks and tests. */
+int venc_time_kernel(venc_ctx *c, int which, int n_items, int iters, float *ms_per_launch);
+
+/* Deterministic synthetic YUV420p source, host side. */
+void venc_synth_frame(int width, int height, int frame_index, uint32_t seed, uint8_t *y, uint8_t *u, uint8_t *v);
+/* same source, generated on the GPU into n_frames consecutive I420 frames in device memory */
+int venc_synth_device(void *d_frames, size_t frame_stride, int width, int height, int first_frame, int n_frames,
+                      uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

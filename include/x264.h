@@ -1,0 +1,139 @@
+/*
+ * x264.h -- source-compatible SUBSET of the libx264 public API, limited to the
+ * names the reference program touches, implemented by libx264_venc.so on top of
+ * the MI355X engine (include/venc_hip.h).
+ *
+ * This header is written for this repository; it is NOT libx264's header and is
+ * not binary compatible with a real libx264.so (struct layouts differ; the real
+ * header is GPL and absent from the build image).  Each declaration cites the
+ * reference call site it serves (file av_encode.c of arkanis/video-encoder):
+ *
+ *   x264_param_default_preset   :384      x264_param_apply_profile  :403
+ *   x264_encoder_open           :408      x264_picture_alloc        :415
+ *   x264_encoder_encode         :970, :1078
+ *   x264_encoder_delayed_frames :1076     x264_picture_clean        :442
+ *   x264_encoder_close          :443
+ *
+ * Fields read/written by the reference: x264_param_t {i_width, i_height,
+ * b_annexb, i_fps_num, i_fps_den, vui.i_sar_width, vui.i_sar_height,
+ * rc.i_rc_method, rc.f_rf_constant} (:389-401); x264_picture_t {i_type, i_pts,
+ * i_dts, b_keyframe, img.plane[], img.i_stride[]} (:543-547, :775-783);
+ * x264_nal_t {i_type, i_payload, p_payload} (:682, :703-705, :722).
+ *
+ * Documented deviations: the encoder is a fixed-QP
+ * H.264 Constrained-Baseline subset; X264_RC_CRF maps f_rf_constant to
+ * QP = round(f) clamped to 12..51; presets and tunes are accepted by name but
+ * only "zerolatency" changes behaviour (no output delay).
+ */
+#ifndef X264_VENC_X264_H
+#define X264_VENC_X264_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define X264_BUILD 0 /* not a libx264 build */
+
+typedef struct x264_t x264_t;
+
+enum nal_unit_type_e {
+    NAL_UNKNOWN = 0,
+    NAL_SLICE = 1,
+    NAL_SLICE_IDR = 5,
+    NAL_SEI = 6,
+    NAL_SPS = 7,
+    NAL_PPS = 8,
+    NAL_AUD = 9,
+    NAL_FILLER = 12
+};
+enum nal_priority_e { NAL_PRIORITY_DISPOSABLE = 0, NAL_PRIORITY_LOW = 1, NAL_PRIORITY_HIGH = 2, NAL_PRIORITY_HIGHEST = 3 };
+
+typedef struct x264_nal_t {
+    int i_ref_idc;
+    int i_type;        /* nal_unit_type_e */
+    int i_payload;     /* bytes at p_payload, INCLUDING the 4-byte length prefix / start code */
+    uint8_t *p_payload; /* all NALs of one frame are contiguous, starting at nals[0].p_payload */
+} x264_nal_t;
+
+#define X264_CSP_I420 0x0001
+#define X264_TYPE_AUTO 0x0000
+#define X264_TYPE_IDR 0x0001
+#define X264_TYPE_I 0x0002
+#define X264_TYPE_P 0x0003
+#define X264_RC_CQP 0
+#define X264_RC_CRF 1
+#define X264_RC_ABR 2
+
+typedef struct x264_param_t {
+    int i_width, i_height;
+    int i_csp;
+    int b_annexb;        /* 0: 4-byte big-endian length prefixes (what the reference asks for, :392); 1: start codes */
+    int i_fps_num, i_fps_den;
+    int i_keyint_max;    /* closed GOP length, default 30 */
+    int i_slice_count;   /* MB-row bands per frame, default 8 (independent of the GPU count) */
+    int i_bframe;        /* always 0 */
+    int i_frame_reference; /* always 1 */
+    int b_zerolatency;   /* set by tune "zerolatency": encode returns the frame it was given */
+    struct {
+        int i_sar_width, i_sar_height;
+    } vui;
+    struct {
+        int i_rc_method;
+        int i_qp_constant;   /* X264_RC_CQP */
+        float f_rf_constant; /* X264_RC_CRF: QP = round(f) */
+    } rc;
+    struct {                /* engine extension, not part of libx264 */
+        int i_device;       /* HIP device ordinal */
+        int i_gop_batch;    /* closed GOPs encoded in lock-step (1 = frame-by-frame streaming) */
+    } hip;
+    char psz_preset[16], psz_tune[16], psz_profile[16];
+} x264_param_t;
+
+typedef struct x264_image_t {
+    int i_csp;
+    int i_plane;
+    int i_stride[4];
+    uint8_t *plane[4];
+} x264_image_t;
+
+typedef struct x264_picture_t {
+    int i_type;
+    int i_qpplus1;
+    int b_keyframe;
+    int64_t i_pts;
+    int64_t i_dts;
+    x264_image_t img;
+    void *opaque;
+} x264_picture_t;
+
+/* 0 on success, non-zero for an unknown preset or tune name (:384-386) */
+int x264_param_default_preset(x264_param_t *param, const char *preset, const char *tune);
+/* accepts NULL (:105, :403); only "baseline" (or NULL) is honoured, other known names are accepted and ignored */
+int x264_param_apply_profile(x264_param_t *param, const char *profile);
+/* NULL on failure (:408-412), including "no HIP device": there is no CPU fallback */
+x264_t *x264_encoder_open(x264_param_t *param);
+/* 0 on success; planes live in pinned host memory so ingest is a single DMA (:415, :545-547) */
+int x264_picture_alloc(x264_picture_t *pic, int i_csp, int i_width, int i_height);
+void x264_picture_clean(x264_picture_t *pic);
+/* > 0: total bytes of all NALs of the returned frame; 0: nothing yet; < 0: error.
+ * pic_in == NULL flushes (:1078).  *pp_nal and the payload stay valid until the next call. */
+int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out);
+int x264_encoder_delayed_frames(x264_t *h);
+void x264_encoder_close(x264_t *h);
+
+/* ---- engine extension: frames already resident in HBM (bench, multi-stream servers).
+ * d_frames: consecutive tight I420 frames in device memory.  For every encoded
+ * frame, in display order, sink(user, nals, nal_count, payload_bytes, pic_out)
+ * is called exactly as the reference's muxer would be (av_encode.c:972).
+ * Returns the number of frames delivered, or < 0. */
+typedef int (*x264_venc_sink)(void *user, const x264_nal_t *nals, int nal_count, int payload_bytes,
+                              const x264_picture_t *pic_out);
+int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_stride, int n_frames, int64_t first_pts,
+                              x264_venc_sink sink, void *user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,178 @@
+"""CPU checks of the per-lane device functions (csrc/venc_device.h compiled by
+g++ into libvenc_hostcheck.so -- a TEST artefact, never loaded by the product)
+against the CPU oracle.  This is how the lane-level logic of the HIP kernels is
+verified in a container without a GPU; the kernels themselves are checked by
+tests/test_gpu_parity.py on the GPU box."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def hc(venc):
+    venc.build()
+    L = C.CDLL(venc.LIB_HOSTCHECK)
+    L.hc_synth_pixel.restype = C.c_ubyte
+    L.hc_fdct4.argtypes = [C.c_void_p, C.c_void_p]
+    L.hc_idct4.argtypes = [C.c_void_p, C.c_void_p]
+    L.hc_cavlc_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.hc_ue_bits.argtypes = [C.c_uint, C.c_void_p]
+    L.hc_se_bits.argtypes = [C.c_int, C.c_void_p]
+    L.hc_table.argtypes = [C.c_int, C.c_void_p]
+    L.hc_synth_pixel.argtypes = [C.c_int] * 6 + [C.c_uint]
+    return L
+
+
+def test_transforms_match_oracle(hc, orc):
+    rng = np.random.default_rng(0)
+    L = orc.lib()
+    for _ in range(300):
+        x = rng.integers(-255, 256, 16).astype(np.int32)
+        w = np.zeros(16, np.int32)
+        hc.hc_fdct4(x.ctypes.data, w.ctypes.data)
+        x16, w16 = x.astype(np.int16), np.zeros(16, np.int16)
+        L.orc_fdct4x4(x16.ctypes.data, w16.ctypes.data)
+        assert np.array_equal(w, w16)
+        d = rng.integers(-20000, 20000, 16).astype(np.int32)
+        r, r16 = np.zeros(16, np.int32), np.zeros(16, np.int16)
+        hc.hc_idct4(d.ctypes.data, r.ctypes.data)
+        L.orc_idct4x4(d.ctypes.data, r16.ctypes.data)
+        assert np.array_equal(r, r16)
+
+
+def test_known_answers(hc):
+    # constant block: only the DC coefficient, equal to 16 x value
+    x = np.full(16, 7, np.int32)
+    w = np.zeros(16, np.int32)
+    hc.hc_fdct4(x.ctypes.data, w.ctypes.data)
+    assert w[0] == 112 and not w[1:].any()
+    # inverse of a pure DC of 64*k reconstructs the constant k
+    d = np.zeros(16, np.int32)
+    d[0] = 64 * 5
+    r = np.zeros(16, np.int32)
+    hc.hc_idct4(d.ctypes.data, r.ctypes.data)
+    assert (r == 5).all()
+    assert [hc.hc_zigzag(i) for i in range(16)] == [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]
+
+
+def test_quantiser_matches_oracle(hc, orc):
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+    for qp in range(12, 52):
+        assert hc.hc_chroma_qp(qp) == [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21,
+                                       22, 23, 24, 25, 26, 27, 28, 29, 29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36,
+                                       37, 37, 37, 38, 38, 38, 39, 39, 39, 39][qp]
+        for w in list(rng.integers(-9180, 9181, 40)) + [0, 1, -1, 9180, -9180]:
+            for r in (0, 1, 5, 10, 15):
+                for intra in (0, 1):
+                    assert hc.hc_quant(int(w), qp, r, intra) == L.orc_quant(int(w), qp, r, intra)
+        for lv in (-2063, -7, -1, 0, 1, 3, 100):
+            for r in range(16):
+                assert hc.hc_dequant(lv, qp, r) == L.orc_dequant(lv, qp, r)
+
+
+def _rand_block(rng, max_coef, density, big):
+    c = np.zeros(16, np.int32)
+    n = max_coef
+    mask = rng.random(n) < density
+    mag = rng.integers(1, 2100 if big else 4, n)
+    sign = rng.integers(0, 2, n) * 2 - 1
+    c[:n] = np.where(mask, mag * sign, 0)
+    return c
+
+
+def test_cavlc_block_matches_oracle(hc, orc):
+    L = orc.lib()
+    rng = np.random.default_rng(2)
+    out_h, out_o = np.zeros(128, np.uint8), np.zeros(128, np.uint8)
+    cases = 0
+    for max_coef, first in ((16, 0), (15, 1), (4, 0)):
+        for nC in ((-1,) if max_coef == 4 else (0, 1, 2, 3, 4, 7, 8, 16)):
+            for density in (0.0, 0.1, 0.3, 0.6, 1.0):
+                for big in (False, True):
+                    for _ in range(25):
+                        blk = _rand_block(rng, max_coef, density, big)
+                        c_dev = np.zeros(16, np.int32)
+                        c_dev[first:first + max_coef] = blk[:max_coef]
+                        bits_h = hc.hc_cavlc_block(c_dev.ctypes.data, first, max_coef, nC, out_h.ctypes.data, 128)
+                        c16 = blk[:max_coef].astype(np.int16)
+                        bits_o = L.orc_cavlc_block_bits(c16.ctypes.data, max_coef, nC, out_o.ctypes.data, 128)
+                        assert bits_h == bits_o and bits_h > 0
+                        nb = (bits_h + 7) // 8
+                        assert bytes(out_h[:nb]) == bytes(out_o[:nb]), (max_coef, nC, blk)
+                        cases += 1
+    assert cases > 2000
+
+
+def test_exp_golomb(hc):
+    buf = np.zeros(16, np.uint8)
+    known = {0: "1", 1: "010", 2: "011", 3: "00100", 6: "00111", 7: "0001000", 32399: None}
+    for v, s in known.items():
+        bits = hc.hc_ue_bits(v, buf.ctypes.data)
+        got = "".join("{:08b}".format(b) for b in buf[:(bits + 7) // 8])[:bits]
+        if s is not None:
+            assert got == s
+        assert bits == 2 * int(np.floor(np.log2(v + 1))) + 1
+    for v, s in {0: "1", 1: "010", -1: "011", 2: "00100", -2: "00101"}.items():
+        bits = hc.hc_se_bits(v, buf.ctypes.data)
+        assert "".join("{:08b}".format(b) for b in buf[:(bits + 7) // 8])[:bits] == s
+
+
+def _check_prefix_code(entries, complete_minus=None):
+    """entries: list of (len, bits) with len > 0.  Prefix-free; Kraft sum = 1 - 2^-complete_minus (or 1)."""
+    from fractions import Fraction
+    k = sum(Fraction(1, 1 << l) for l, _ in entries)
+    for i, (l1, b1) in enumerate(entries):
+        assert b1 < (1 << l1)
+        for j, (l2, b2) in enumerate(entries):
+            if i != j and l2 >= l1:
+                assert (b2 >> (l2 - l1)) != b1, "prefix clash"
+    expect = Fraction(1) - (Fraction(1, 1 << complete_minus) if complete_minus else 0)
+    assert k == expect, (k, expect)
+
+
+def test_product_vlc_tables_structure(hc):
+    buf = (C.c_ushort * 272)()
+
+    def tab(which):
+        n = hc.hc_table(which, buf)
+        return [(buf[i] >> 8, buf[i] & 0xff) for i in range(n)]
+    ct = tab(0)
+    for t, missing in enumerate((15, 13, 10, None)):
+        ent = [e for e in ct[68 * t:68 * t + 68] if e[0]]
+        assert len(ent) == 62
+        if missing:
+            _check_prefix_code(ent, missing)      # only the all-zero codeword is unused
+        else:
+            assert all(l == 6 for l, _ in ent) and len({b for _, b in ent}) == 62
+    _check_prefix_code([e for e in tab(1) if e[0]])
+    tz = tab(2)
+    for t in range(15):
+        ent = [e for e in tz[16 * t:16 * t + 16] if e[0]]
+        assert len(ent) == 16 - t
+        _check_prefix_code(ent, 9 if t == 0 else None)
+    tzc = tab(3)
+    for t in range(3):
+        _check_prefix_code([e for e in tzc[4 * t:4 * t + 4] if e[0]])
+    rb = tab(4)
+    for t in range(7):
+        ent = [e for e in rb[16 * t:16 * t + 16] if e[0]]
+        assert len(ent) == (t + 2 if t < 6 else 15)
+        _check_prefix_code(ent, 11 if t == 6 else None)
+    assert sorted(hc.hc_cbp_code(c) for c in range(48)) == list(range(48))
+    assert hc.hc_cbp_code(0) == 0 and hc.hc_cbp_code(47) == 12 and hc.hc_cbp_code(16) == 1
+
+
+def test_synth_source_is_deterministic_and_in_range(hc, venc):
+    w, h = 64, 48
+    y, u, v = venc.synth_frame(w, h, 5, 0x1234ABCD)
+    y2, _, _ = venc.synth_frame(w, h, 5, 0x1234ABCD)
+    assert np.array_equal(y, y2)
+    for (x, yy) in ((0, 0), (17, 31), (63, 47)):
+        assert y[yy, x] == hc.hc_synth_pixel(0, x, yy, 5, w, h, 0x1234ABCD)
+    assert u[3, 9] == hc.hc_synth_pixel(1, 9, 3, 5, w, h, 0x1234ABCD)
+    assert v[3, 9] == hc.hc_synth_pixel(2, 9, 3, 5, w, h, 0x1234ABCD)
+    y3, _, _ = venc.synth_frame(w, h, 6, 0x1234ABCD)
+    assert not np.array_equal(y, y3)
+    assert 8 <= y.min() and y.max() <= 245

@@ -1,0 +1,166 @@
+"""GPU parity tests (-m gpu): every HIP stage and the final bitstream must be
+bit-exact against the CPU oracle (oracle/, PARITY UNPINNED w.r.t. libx264 --
+the oracle is this repository's own restatement, see oracle/orc.h).
+
+All calls go through the C-ABI: include/venc_hip.h for the stage-level checks,
+include/x264.h (the reference's own entry points, av_encode.c:970) for the
+frame-in / bitstream-out checks.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import noise_frames, split_nals, unescape
+
+pytestmark = pytest.mark.gpu
+
+
+def _clip(venc, w, h, n, seed, kind):
+    if kind == "synth":
+        return [venc.synth_frame(w, h, t, seed) for t in range(n)]
+    return noise_frames(w, h, n, seed)
+
+
+def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x1234ABCD):
+    enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=keyint, threads=8)
+    eng = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2)
+    frames = _clip(venc, w, h, n, seed, kind)
+    for t, (y, u, v) in enumerate(frames):
+        ref = enc.encode(y, u, v)
+        idr = t % keyint == 0
+        eng.upload(t % 2, y, u, v)
+        eng.encode_step([t % 2], [t % 2], idr, (t % keyint) & 15, [(t // keyint) & 1])
+        eng.sync()
+        tag = "%dx%d qp%d s%d t%d %s" % (w, h, qp, slices, t, "I" if idr else "P")
+        mv, sad = eng.mv_sad()
+        assert np.array_equal(mv, enc.mv()), "mv " + tag
+        if not idr:
+            assert np.array_equal(sad, enc.sad()), "sad " + tag
+        lv_g, lv_o = eng.debug(1), enc.levels()
+        if not np.array_equal(lv_g, lv_o):
+            bad = np.argwhere(lv_g != lv_o)
+            raise AssertionError("levels %s first mismatch mb,blk,idx=%s gpu=%d orc=%d (%d diffs)" % (
+                tag, bad[0], lv_g[tuple(bad[0])], lv_o[tuple(bad[0])], len(bad)))
+        rec_o = enc.recon()
+        for p in range(3):
+            assert np.array_equal(eng.debug(4 + p), rec_o[p]), "recon plane %d %s" % (p, tag)
+        # macroblock bit counts (the first MB of a slice also carries the slice header on the GPU)
+        bits_g, bits_o = eng.debug(3).astype(np.int64), enc.mb_bits().astype(np.int64)
+        first = set(int(r) * enc.mbw for r in enc.slice_rows()[:-1])
+        idx = np.array([i for i in range(enc.nmb) if i not in first])
+        if not np.array_equal(bits_g[idx], bits_o[idx]):
+            bad = idx[np.nonzero(bits_g[idx] != bits_o[idx])[0]]
+            raise AssertionError("mb bits %s: first bad mb %d gpu %d orc %d (%d bad)" % (
+                tag, bad[0], bits_g[bad[0]], bits_o[bad[0]], len(bad)))
+        # slice RBSPs
+        sl_g = eng.get_slices(t % 2)
+        sl_o = [unescape(b) for (ty, _, b) in split_nals(ref.data) if ty in (1, 5)]
+        assert len(sl_g) == len(sl_o), "slice count " + tag
+        for s, (a, b) in enumerate(zip(sl_g, sl_o)):
+            assert a == b, "slice %d rbsp %s (len gpu %d orc %d)" % (s, tag, len(a), len(b))
+    eng.close()
+
+
+@pytest.mark.parametrize("w,h,qp,slices,keyint,n,kind", [
+    (352, 288, 26, 4, 4, 6, "synth"),      # CIF, I + P, multi-slice
+    (352, 288, 26, 1, 1, 2, "synth"),      # config 1 shape: I frames only, single slice
+    (176, 144, 12, 9, 3, 5, "noise"),      # minimum QP, one slice per MB row
+    (176, 144, 51, 2, 3, 4, "noise"),      # maximum QP
+    (178, 146, 30, 3, 3, 4, "noise"),      # not a multiple of 16 nor of 4: clamped ingest paths
+    (640, 368, 38, 23, 2, 3, "synth"),     # chroma QP table region, many slices
+    (1920, 1080, 26, 8, 2, 2, "synth"),    # BASELINE config 2 geometry
+])
+def test_stages_match_oracle(venc, orc, w, h, qp, slices, keyint, n, kind):
+    _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind)
+
+
+def _x264_stream(venc, frames, w, h, **kw):
+    e = venc.X264Encoder(w, h, **kw)
+    out = []
+    for t, (y, u, v) in enumerate(frames):
+        r = e.encode(y, u, v, t)
+        if r is not None:
+            out.append(r)
+    assert e.delayed_frames() == len(frames) - len(out)
+    out += e.flush()
+    assert e.delayed_frames() == 0
+    e.close()
+    return out
+
+
+@pytest.mark.parametrize("w,h,qp,slices,keyint,n,gop_batch,tune", [
+    (352, 288, 26, 8, 30, 30, 1, "film"),          # config 1/2 shape at CIF
+    (352, 288, 20, 8, 5, 23, 1, "zerolatency"),    # reference default quality 20 (av_encode.c:104)
+    (352, 288, 26, 8, 5, 23, 3, "film"),           # GOP-batched, partial last batch
+    (320, 180, 33, 5, 4, 17, 2, "film"),           # height not a multiple of 16 (cropping)
+])
+def test_x264_api_bitstream_matches_oracle(venc, orc, w, h, qp, slices, keyint, n, gop_batch, tune):
+    frames = [venc.synth_frame(w, h, t) for t in range(n)]
+    enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=keyint, fps=(30, 1), sar=(1, 1), threads=8)
+    dec = orc.Decoder()
+    got = _x264_stream(venc, frames, w, h, qp=qp, slices=slices, keyint=keyint, fps=(30, 1), sar=(1, 1),
+                       gop_batch=gop_batch, tune=tune)
+    assert len(got) == n
+    last_dts = None
+    for t, (y, u, v) in enumerate(frames):
+        ref = enc.encode(y, u, v)
+        g = got[t]
+        assert g.payload == ref.data, "frame %d bitstream differs (gpu %d bytes, oracle %d)" % (
+            t, len(g.payload), len(ref.data))
+        # boundary invariants of SURVEY.md section 8b
+        assert g.keyframe == ref.is_idr and g.pts == t and g.dts == g.pts
+        assert last_dts is None or g.dts > last_dts
+        last_dts = g.dts
+        off = 0
+        for (ty, ref_idc, o, size) in g.nals:
+            assert o == off, "NALs must be contiguous"
+            assert int.from_bytes(g.payload[o:o + 4], "big") == size - 4
+            off += size
+        assert off == len(g.payload)
+        if g.keyframe:
+            assert [n_[0] for n_ in g.nals[:2]] == [7, 8]
+            sps = g.payload[g.nals[0][2]:]
+            assert sps[5] == 66 and sps[6] == 0xC0
+        assert dec.decode(g.payload) == 1
+        assert np.array_equal(dec.planes()[0], enc.recon()[0])
+
+
+def test_gop_batched_equals_streaming(venc):
+    w, h, n = 352, 288, 40
+    frames = [venc.synth_frame(w, h, t, 99) for t in range(n)]
+    a = _x264_stream(venc, frames, w, h, qp=28, slices=6, keyint=8, gop_batch=1)
+    b = _x264_stream(venc, frames, w, h, qp=28, slices=6, keyint=8, gop_batch=4)
+    assert [f.payload for f in a] == [f.payload for f in b]
+
+
+def test_resident_full_size_roundtrip(venc, orc):
+    """BASELINE config 2 geometry at full size: size-independent properties --
+    own decoder reproduces a decodable stream, GOP-batched == streaming hash,
+    and the device-side synthetic source equals the host one."""
+    import torch
+    w, h, n, keyint = 1920, 1080, 12, 6
+    fb = w * h * 3 // 2
+    buf = torch.empty(n * fb, dtype=torch.uint8, device="cuda")
+    assert venc.hip_lib().venc_synth_device(buf.data_ptr(), fb, w, h, 0, n, 0x1234ABCD) == 0
+    host = buf.cpu().numpy().reshape(n, fb)
+    y0, u0, v0 = venc.synth_frame(w, h, 3)
+    assert np.array_equal(host[3][:w * h].reshape(h, w), y0)
+    assert np.array_equal(host[3][w * h:w * h * 5 // 4].reshape(h // 2, w // 2), u0)
+    hashes = []
+    for gb in (1, 2):
+        e = venc.X264Encoder(w, h, qp=26, slices=8, keyint=keyint, gop_batch=gb)
+        dec = orc.Decoder()
+        md = hashlib.sha256()
+        sizes = []
+
+        def sink(payload, nals, pts, key, md=md, dec=dec, sizes=sizes):
+            md.update(payload)
+            sizes.append(len(payload))
+            assert dec.decode(payload) == 1
+            assert key == (pts % keyint == 0)
+        assert e.encode_resident(buf.data_ptr(), fb, n, sink) == n
+        assert dec.size() == (w, h)
+        e.close()
+        hashes.append(md.hexdigest())
+    assert hashes[0] == hashes[1]

@@ -1,0 +1,256 @@
+/*
+ * encode_yuv.c -- C driver that replays the reference program's video path
+ * against libx264_venc.so, call for call:
+ *
+ *   open      enc_x264_open            av_encode.c:378-438 (called at :895)
+ *   ingest    pic_in.i_type/i_pts + plane copy   :543-547
+ *   encode    x264_encoder_encode      :970-975
+ *   mux       enc_mp4_mux_video / enc_mp4_write_video_sample   :762-834, :670-751
+ *   flush     delayed-frames loop      :1076-1083, final mux flush :1087-1088
+ *   close     enc_x264_close           :440-444 (called at :1120)
+ *
+ * The reference's demux/decode/filter stages (libav*) and its MP4 writer
+ * (libmp4v2) are out of scope; frames come from a raw
+ * I420 file or the built-in synthetic source, and the "muxer" below keeps the
+ * reference's one-frame hold-back logic and checks every invariant the real
+ * one relies on before writing the samples as an
+ * Annex-B elementary stream (or nothing with -o -).
+ *
+ * usage: encode_yuv [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint]
+ *                   [-g gop_batch] [-t tune] [-i in.yuv] [-o out.h264] [-f fps]
+ */
+#define _POSIX_C_SOURCE 200809L
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "venc_hip.h"
+#include "x264.h"
+
+typedef struct {
+    x264_t *encoder;
+    x264_picture_t pic_in, pic_out;
+    x264_nal_t *nals;
+    int nal_count;
+    int payload_size;
+} x264_context_t; /* av_encode.c:369-376 without the swscale handle */
+
+static bool enc_x264_open(int width, int height, int fps_num, int fps_den, const char *preset, const char *tune, int quality,
+                          const char *profile, int slices, int keyint, int gop_batch, x264_context_t *x) {
+    x264_param_t params;
+    if (x264_param_default_preset(&params, preset, tune) != 0) {
+        fprintf(stderr, "x264: failed to set preset %s and tune %s\n", preset, tune);
+        return false;
+    }
+    params.i_width = width;
+    params.i_height = height;
+    params.b_annexb = false;
+    params.i_fps_num = fps_num;
+    params.i_fps_den = fps_den;
+    params.vui.i_sar_width = 1;
+    params.vui.i_sar_height = 1;
+    params.rc.i_rc_method = X264_RC_CRF;
+    params.rc.f_rf_constant = (float)quality;
+    params.i_slice_count = slices;
+    params.i_keyint_max = keyint;
+    params.hip.i_gop_batch = gop_batch;
+    if (x264_param_apply_profile(&params, profile) != 0) {
+        fprintf(stderr, "x264: failed to apply profile %s\n", profile);
+        return false;
+    }
+    x->encoder = x264_encoder_open(&params);
+    if (x->encoder == NULL) {
+        fprintf(stderr, "x264: failed to initialize encoder\n");
+        return false;
+    }
+    if (x264_picture_alloc(&x->pic_in, X264_CSP_I420, width, height) != 0) {
+        fprintf(stderr, "x264: could not allocate input picture\n");
+        return false;
+    }
+    x->pic_out.i_pts = 0;
+    return true;
+}
+
+static void enc_x264_close(x264_context_t *x) {
+    x264_picture_clean(&x->pic_in);
+    x264_encoder_close(x->encoder);
+}
+
+/* ---- muxer stand-in with the reference's structure and its assumptions made explicit ---- */
+typedef struct {
+    uint8_t *payload_data;
+    size_t payload_size;
+    x264_nal_t *nal_data;
+    size_t nal_count;
+    x264_picture_t pic;
+} x264_frame_t;
+
+static FILE *g_out = NULL;
+static long g_samples = 0, g_sync_samples = 0, g_bytes = 0, g_violations = 0;
+static bool g_track_configured = false;
+
+#define REQUIRE(cond, msg)                                   \
+    do {                                                     \
+        if (!(cond)) {                                       \
+            fprintf(stderr, "boundary violation: %s\n", msg); \
+            g_violations++;                                  \
+        }                                                    \
+    } while (0)
+
+static void write_sample(x264_nal_t *nals, int nal_count, size_t payload_size, bool is_sync, int64_t decode_delta,
+                         int64_t composition_offset) {
+    static const uint8_t startcode[4] = {0, 0, 0, 1};
+    REQUIRE(decode_delta > 0, "dts must increase strictly (sample duration = delta dts)");
+    REQUIRE(composition_offset >= 0, "pts - dts must be >= 0");
+    for (int i = 0; i < nal_count; i++) {
+        x264_nal_t *n = &nals[i];
+        const uint32_t len = ((uint32_t)n->p_payload[0] << 24) | ((uint32_t)n->p_payload[1] << 16) | ((uint32_t)n->p_payload[2] << 8) | n->p_payload[3];
+        REQUIRE((int)len + 4 == n->i_payload, "i_payload must include the 4-byte length prefix");
+        REQUIRE((n->p_payload[4] & 31) == n->i_type, "NAL header type must match i_type");
+        switch (n->i_type) {
+            case NAL_SPS:
+                if (!g_track_configured) {
+                    REQUIRE(n->p_payload[5] == 66, "SPS byte 5 = profile_idc");
+                    REQUIRE(n->p_payload[7] >= 10 && n->p_payload[7] <= 52, "SPS byte 7 = level_idc");
+                    g_track_configured = true;
+                }
+                /* fallthrough: parameter sets go to the elementary stream too */
+            case NAL_PPS:
+                if (g_out) {
+                    fwrite(startcode, 1, 4, g_out);
+                    fwrite(n->p_payload + 4, 1, (size_t)n->i_payload - 4, g_out);
+                }
+                break;
+            case NAL_FILLER:
+                break;
+            default: {
+                int remaining = nal_count - i;
+                uint8_t *start = nals[i].p_payload;
+                long size = (long)payload_size - (long)(start - nals[0].p_payload);
+                long sum = 0;
+                for (int k = i; k < nal_count; k++) {
+                    REQUIRE(nals[k].p_payload == start + sum, "NAL payloads must be contiguous");
+                    REQUIRE(nals[k].i_type != NAL_SPS && nals[k].i_type != NAL_PPS, "parameter sets must precede slices");
+                    if (g_out) {
+                        fwrite(startcode, 1, 4, g_out);
+                        fwrite(nals[k].p_payload + 4, 1, (size_t)nals[k].i_payload - 4, g_out);
+                    }
+                    sum += nals[k].i_payload;
+                }
+                REQUIRE(sum == size, "sample size computed by pointer subtraction must cover exactly the remaining NALs");
+                g_samples++;
+                g_sync_samples += is_sync;
+                g_bytes += size;
+                i += remaining;
+            } break;
+        }
+    }
+}
+
+static bool mux_video(x264_context_t *x) {
+    static x264_frame_t prev = {NULL, 0, NULL, 0, {0}};
+    if (x->payload_size > 0) {
+        if (prev.payload_size > 0)
+            write_sample(prev.nal_data, (int)prev.nal_count, prev.payload_size, prev.pic.b_keyframe,
+                         x->pic_out.i_dts - prev.pic.i_dts, prev.pic.i_pts - prev.pic.i_dts);
+        free(prev.payload_data);
+        free(prev.nal_data);
+        prev.payload_data = (uint8_t *)malloc((size_t)x->payload_size);
+        prev.nal_data = (x264_nal_t *)malloc((size_t)x->nal_count * sizeof(x264_nal_t));
+        if (!prev.payload_data || !prev.nal_data) return false;
+        memcpy(prev.payload_data, x->nals[0].p_payload, (size_t)x->payload_size);
+        prev.payload_size = (size_t)x->payload_size;
+        prev.pic = x->pic_out;
+        prev.nal_count = (size_t)x->nal_count;
+        for (int i = 0; i < x->nal_count; i++) {
+            prev.nal_data[i] = x->nals[i];
+            prev.nal_data[i].p_payload = prev.payload_data + (x->nals[i].p_payload - x->nals[0].p_payload);
+        }
+    } else if (prev.payload_size > 0) {
+        write_sample(prev.nal_data, (int)prev.nal_count, prev.payload_size, prev.pic.b_keyframe, 1, prev.pic.i_pts - prev.pic.i_dts);
+        free(prev.payload_data);
+        free(prev.nal_data);
+        prev.payload_data = NULL;
+        prev.nal_data = NULL;
+        prev.payload_size = 0;
+    }
+    return true;
+}
+
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+int main(int argc, char **argv) {
+    int w = 352, h = 288, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 1, fps = 30;
+    const char *in = NULL, *out = NULL, *tune = "film";
+    for (int i = 1; i < argc; i++) {
+        const char *a = argv[i], *v = i + 1 < argc ? argv[i + 1] : NULL;
+        if (!strcmp(a, "-s") && v && sscanf(v, "%dx%d", &w, &h) == 2) i++;
+        else if (!strcmp(a, "-n") && v) frames = atoi(v), i++;
+        else if (!strcmp(a, "-q") && v) qp = atoi(v), i++;
+        else if (!strcmp(a, "-S") && v) slices = atoi(v), i++;
+        else if (!strcmp(a, "-k") && v) keyint = atoi(v), i++;
+        else if (!strcmp(a, "-g") && v) gop_batch = atoi(v), i++;
+        else if (!strcmp(a, "-f") && v) fps = atoi(v), i++;
+        else if (!strcmp(a, "-t") && v) tune = v, i++;
+        else if (!strcmp(a, "-i") && v) in = v, i++;
+        else if (!strcmp(a, "-o") && v) out = v, i++;
+        else {
+            fprintf(stderr, "usage: %s [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint] [-g gop_batch] [-t tune] [-f fps] [-i in.yuv] [-o out.h264]\n", argv[0]);
+            return 1;
+        }
+    }
+    FILE *fin = NULL;
+    if (in && !(fin = fopen(in, "rb"))) {
+        perror(in);
+        return 2;
+    }
+    if (out && strcmp(out, "-") && !(g_out = fopen(out, "wb"))) {
+        perror(out);
+        return 2;
+    }
+    x264_context_t x264;
+    memset(&x264, 0, sizeof(x264));
+    if (!enc_x264_open(w, h, fps, 1, "medium", tune, qp, NULL, slices, keyint, gop_batch, &x264)) return 6;
+
+    const double t0 = now_s();
+    int64_t encoded_video_pts = 0;
+    for (int f = 0; f < frames; f++) {
+        x264.pic_in.i_type = X264_TYPE_AUTO;
+        x264.pic_in.i_pts = f;
+        if (fin) {
+            size_t want = (size_t)w * h * 3 / 2;
+            if (fread(x264.pic_in.img.plane[0], 1, want, fin) != want) break;
+        } else {
+            venc_synth_frame(w, h, f, 0x1234ABCDu, x264.pic_in.img.plane[0], x264.pic_in.img.plane[1], x264.pic_in.img.plane[2]);
+        }
+        x264.payload_size = x264_encoder_encode(x264.encoder, &x264.nals, &x264.nal_count, &x264.pic_in, &x264.pic_out);
+        if (x264.payload_size > 0)
+            mux_video(&x264);
+        else if (x264.payload_size < 0)
+            fprintf(stderr, "x264: encoder error\n");
+        encoded_video_pts = x264.pic_out.i_pts;
+    }
+    while (x264_encoder_delayed_frames(x264.encoder) > 0) {
+        x264.payload_size = x264_encoder_encode(x264.encoder, &x264.nals, &x264.nal_count, NULL, &x264.pic_out);
+        if (x264.payload_size > 0)
+            mux_video(&x264);
+        else if (x264.payload_size < 0)
+            fprintf(stderr, "x264: encoder error");
+    }
+    x264.payload_size = 0;
+    mux_video(&x264);
+    const double dt = now_s() - t0;
+    enc_x264_close(&x264);
+    if (g_out) fclose(g_out);
+    if (fin) fclose(fin);
+    printf("{\"frames\": %ld, \"sync_samples\": %ld, \"bytes\": %ld, \"last_pts\": %lld, \"seconds\": %.4f, \"mpixels_per_s\": %.2f, \"violations\": %ld}\n",
+           g_samples, g_sync_samples, g_bytes, (long long)encoded_video_pts, dt, g_samples * (double)w * h / dt / 1e6, g_violations);
+    return g_violations ? 3 : 0;
+}

@@ -1,0 +1,363 @@
+"""video-encoder_amd -- MI355X-native macroblock encode loop behind the x264 entry points.
+
+Host-side Python mirror of the two C interfaces of this repository:
+
+* :class:`Engine`      -- include/venc_hip.h, the thin C-ABI of the HIP kernels
+                          (frame slots in HBM -> slice RBSPs in pinned memory);
+* :class:`X264Encoder` -- include/x264.h, the subset of the x264 API the
+                          reference program calls (av_encode.c:384-443, :970,
+                          :1076-1078), implemented in C by csrc/x264_shim.c.
+
+Python is plumbing here (ctypes + numpy); all arithmetic runs in the HIP
+kernels of csrc/venc_kernels.hip.  There is no CPU fallback: if the shared
+libraries are missing or no HIP device is present, construction raises.
+
+The package directory name contains a hyphen, import it with
+``importlib.import_module("video-encoder_amd")``.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_HIP = os.path.join(CSRC, "libvenc_hip.so")
+LIB_X264 = os.path.join(CSRC, "libx264_venc.so")
+LIB_HOSTCHECK = os.path.join(CSRC, "libvenc_hostcheck.so")
+
+MB_COEFS = 27 * 16
+MAX_ITEMS = 64
+
+
+class VencError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile every native component in-tree (hipcc --offload-arch=gfx950, gcc)."""
+    cmd = ["make", "-C", CSRC] + ([] if verbose else ["-s"])
+    subprocess.check_call(cmd)
+    tools = os.path.join(os.path.dirname(_HERE), "tools")
+    if os.path.exists(os.path.join(tools, "Makefile")):
+        subprocess.check_call(["make", "-C", tools] + ([] if verbose else ["-s"]))
+
+
+# ----------------------------------------------------------------------------- C-ABI structs
+class VencConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "max_items", "in_slots", "out_slots",
+                                       "device")]
+
+
+class VencSlice(C.Structure):
+    _fields_ = [("byte_off", C.c_uint32), ("nbytes", C.c_uint32), ("nbits", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class VencFrame(C.Structure):
+    _fields_ = [("data", C.POINTER(C.c_uint8)), ("slices", C.POINTER(VencSlice)), ("n_slices", C.c_uint32),
+                ("total_bytes", C.c_uint32), ("error", C.c_uint32)]
+
+
+class X264Nal(C.Structure):
+    _fields_ = [("i_ref_idc", C.c_int), ("i_type", C.c_int), ("i_payload", C.c_int),
+                ("p_payload", C.POINTER(C.c_uint8))]
+
+
+class _Vui(C.Structure):
+    _fields_ = [("i_sar_width", C.c_int), ("i_sar_height", C.c_int)]
+
+
+class _Rc(C.Structure):
+    _fields_ = [("i_rc_method", C.c_int), ("i_qp_constant", C.c_int), ("f_rf_constant", C.c_float)]
+
+
+class _Hip(C.Structure):
+    _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int)]
+
+
+class X264Param(C.Structure):
+    _fields_ = [("i_width", C.c_int), ("i_height", C.c_int), ("i_csp", C.c_int), ("b_annexb", C.c_int),
+                ("i_fps_num", C.c_int), ("i_fps_den", C.c_int), ("i_keyint_max", C.c_int), ("i_slice_count", C.c_int),
+                ("i_bframe", C.c_int), ("i_frame_reference", C.c_int), ("b_zerolatency", C.c_int), ("vui", _Vui),
+                ("rc", _Rc), ("hip", _Hip), ("psz_preset", C.c_char * 16), ("psz_tune", C.c_char * 16),
+                ("psz_profile", C.c_char * 16)]
+
+
+class X264Image(C.Structure):
+    _fields_ = [("i_csp", C.c_int), ("i_plane", C.c_int), ("i_stride", C.c_int * 4),
+                ("plane", C.POINTER(C.c_uint8) * 4)]
+
+
+class X264Picture(C.Structure):
+    _fields_ = [("i_type", C.c_int), ("i_qpplus1", C.c_int), ("b_keyframe", C.c_int), ("i_pts", C.c_int64),
+                ("i_dts", C.c_int64), ("img", X264Image), ("opaque", C.c_void_p)]
+
+
+X264_CSP_I420 = 1
+X264_TYPE_AUTO = 0
+X264_RC_CQP, X264_RC_CRF = 0, 1
+NAL_SLICE, NAL_SLICE_IDR, NAL_SPS, NAL_PPS, NAL_FILLER = 1, 5, 7, 8, 12
+
+SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(X264Nal), C.c_int, C.c_int, C.POINTER(X264Picture))
+
+_hip = None
+_x264 = None
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise VencError("%s is missing: run __graft_entry__.build() (make -C %s). "
+                        "The HIP path has no CPU fallback." % (path, CSRC))
+    return C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        L = _load(LIB_HIP)
+        L.venc_last_error.restype = C.c_char_p
+        L.venc_open.argtypes = [C.POINTER(VencConfig), C.POINTER(C.c_void_p)]
+        L.venc_close.argtypes = [C.c_void_p]
+        for n in ("venc_mb_width", "venc_mb_height", "venc_n_slices", "venc_upload_sync", "venc_mark", "venc_sync"):
+            getattr(L, n).argtypes = [C.c_void_p]
+        L.venc_frame_bytes.restype = C.c_size_t
+        L.venc_frame_bytes.argtypes = [C.c_void_p]
+        L.venc_upload.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.venc_set_input.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        L.venc_input_slot_ptr.restype = C.c_void_p
+        L.venc_input_slot_ptr.argtypes = [C.c_void_p, C.c_int]
+        L.venc_host_alloc.restype = C.c_void_p
+        L.venc_host_alloc.argtypes = [C.c_size_t]
+        L.venc_host_free.argtypes = [C.c_void_p]
+        L.venc_encode_step.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int, C.c_int,
+                                       C.POINTER(C.c_int)]
+        L.venc_wait.argtypes = [C.c_void_p, C.c_int]
+        L.venc_get_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(VencFrame)]
+        L.venc_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.venc_synth_frame.restype = None
+        L.venc_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.venc_synth_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        _hip = L
+    return _hip
+
+
+def x264_lib():
+    global _x264
+    if _x264 is None:
+        hip_lib()
+        L = _load(LIB_X264)
+        L.x264_param_default_preset.argtypes = [C.POINTER(X264Param), C.c_char_p, C.c_char_p]
+        L.x264_param_apply_profile.argtypes = [C.POINTER(X264Param), C.c_char_p]
+        L.x264_encoder_open.restype = C.c_void_p
+        L.x264_encoder_open.argtypes = [C.POINTER(X264Param)]
+        L.x264_picture_alloc.argtypes = [C.POINTER(X264Picture), C.c_int, C.c_int, C.c_int]
+        L.x264_picture_clean.restype = None
+        L.x264_picture_clean.argtypes = [C.POINTER(X264Picture)]
+        L.x264_encoder_encode.argtypes = [C.c_void_p, C.POINTER(C.POINTER(X264Nal)), C.POINTER(C.c_int),
+                                          C.POINTER(X264Picture), C.POINTER(X264Picture)]
+        L.x264_encoder_delayed_frames.argtypes = [C.c_void_p]
+        L.x264_encoder_close.restype = None
+        L.x264_encoder_close.argtypes = [C.c_void_p]
+        L.x264_venc_encode_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int64, SINK_FN,
+                                                C.c_void_p]
+        _x264 = L
+    return _x264
+
+
+def synth_frame(width, height, frame_index, seed=0x1234ABCD):
+    """Deterministic synthetic YUV420p frame (host implementation of csrc/venc_synth.h)."""
+    y = np.empty((height, width), np.uint8)
+    u = np.empty((height // 2, width // 2), np.uint8)
+    v = np.empty((height // 2, width // 2), np.uint8)
+    hip_lib().venc_synth_frame(width, height, frame_index, seed, y.ctypes.data, u.ctypes.data, v.ctypes.data)
+    return y, u, v
+
+
+# ----------------------------------------------------------------------------- Engine (venc_hip.h)
+class Engine:
+    """One encoder context on one GPU: frame slots in, slice RBSPs out."""
+
+    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0):
+        self.L = hip_lib()
+        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device)
+        h = C.c_void_p()
+        rc = self.L.venc_open(C.byref(self.cfg), C.byref(h))
+        if rc != 0:
+            raise VencError("venc_open failed (%d): %s" % (rc, self.L.venc_last_error().decode()))
+        self.h = h
+        self.width, self.height = width, height
+        self.mbw, self.mbh = self.L.venc_mb_width(h), self.L.venc_mb_height(h)
+        self.nmb = self.mbw * self.mbh
+        self.n_slices = self.L.venc_n_slices(h)
+        self.frame_bytes = self.L.venc_frame_bytes(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.venc_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _ok(self, rc, what):
+        if rc < 0:
+            raise VencError("%s failed (%d): %s" % (what, rc, self.L.venc_last_error().decode()))
+        return rc
+
+    def upload(self, slot, y, u, v):
+        y, u, v = (np.ascontiguousarray(a, np.uint8) for a in (y, u, v))
+        self._ok(self.L.venc_upload(self.h, slot, y.ctypes.data, y.strides[0], u.ctypes.data, u.strides[0],
+                                    v.ctypes.data, v.strides[0]), "venc_upload")
+        self._ok(self.L.venc_upload_sync(self.h), "venc_upload_sync")
+
+    def set_input(self, dev_ptr, frame_stride, n_frames):
+        self._ok(self.L.venc_set_input(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames), "venc_set_input")
+
+    def input_slot_ptr(self, slot):
+        return self.L.venc_input_slot_ptr(self.h, slot)
+
+    def encode_step(self, in_slots, out_slots, is_idr, frame_num, idr_ids=None):
+        n = len(in_slots)
+        a = (C.c_int * n)(*in_slots)
+        b = (C.c_int * n)(*out_slots)
+        c = (C.c_int * n)(*(idr_ids if idr_ids is not None else [0] * n))
+        self._ok(self.L.venc_encode_step(self.h, n, a, b, int(bool(is_idr)), frame_num, c), "venc_encode_step")
+
+    def mark(self):
+        return self._ok(self.L.venc_mark(self.h), "venc_mark")
+
+    def wait(self, ticket):
+        self._ok(self.L.venc_wait(self.h, ticket), "venc_wait")
+
+    def sync(self):
+        self._ok(self.L.venc_sync(self.h), "venc_sync")
+
+    def get_slices(self, out_slot):
+        """Slice RBSPs (bytes) of an output slot."""
+        f = VencFrame()
+        self._ok(self.L.venc_get_frame(self.h, out_slot, C.byref(f)), "venc_get_frame")
+        out = []
+        for s in range(f.n_slices):
+            sl = f.slices[s]
+            out.append(bytes(np.ctypeslib.as_array(f.data, (f.total_bytes,))[sl.byte_off:sl.byte_off + sl.nbytes]))
+        return out
+
+    def debug(self, what, item=0):
+        cw, ch = self.mbw * 16, self.mbh * 16
+        shapes = {0: ((self.nmb,), np.uint32), 1: ((self.nmb, 27, 16), np.int16), 2: ((self.nmb, 32), np.uint8),
+                  3: ((self.nmb,), np.uint32), 4: ((ch, cw), np.uint8), 5: ((ch // 2, cw // 2), np.uint8),
+                  6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32)}
+        shape, dt = shapes[what]
+        a = np.empty(shape, dt)
+        self._ok(self.L.venc_debug_read(self.h, what, item, a.ctypes.data, a.nbytes), "venc_debug_read")
+        return a
+
+    def mv_sad(self, item=0):
+        m = self.debug(0, item)
+        dx = (m & 0xff).astype(np.int8)
+        dy = ((m >> 8) & 0xff).astype(np.int8)
+        return np.stack([dx, dy], axis=1), (m >> 16).astype(np.uint16)
+
+
+# ----------------------------------------------------------------------------- X264Encoder (x264.h)
+class EncodedFrame:
+    def __init__(self, payload, nals, pts, dts, keyframe):
+        self.payload = payload      # bytes: all NALs, contiguous
+        self.nals = nals            # list of (type, ref_idc, offset, size)
+        self.pts, self.dts, self.keyframe = pts, dts, keyframe
+
+
+class X264Encoder:
+    """Mirror of the reference's x264_context_t usage (av_encode.c:369-444, :543-547, :968-975, :1076-1083)."""
+
+    def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
+                 tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None):
+        self.L = x264_lib()
+        p = X264Param()
+        if self.L.x264_param_default_preset(C.byref(p), preset.encode() if preset else None,
+                                            tune.encode() if tune else None) != 0:
+            raise ValueError("x264: failed to set preset %s and tune %s" % (preset, tune))
+        p.i_width, p.i_height = width, height
+        p.b_annexb = int(annexb)
+        p.i_fps_num, p.i_fps_den = fps
+        p.vui.i_sar_width, p.vui.i_sar_height = sar
+        if crf is not None:
+            p.rc.i_rc_method, p.rc.f_rf_constant = X264_RC_CRF, float(crf)
+        else:
+            p.rc.i_rc_method, p.rc.i_qp_constant = X264_RC_CQP, qp
+        p.i_keyint_max, p.i_slice_count = keyint, slices
+        p.hip.i_device, p.hip.i_gop_batch = device, gop_batch
+        if self.L.x264_param_apply_profile(C.byref(p), profile.encode() if profile else None) != 0:
+            raise ValueError("x264: failed to apply profile %s" % profile)
+        self.param = p
+        self.h = self.L.x264_encoder_open(C.byref(p))
+        if not self.h:
+            raise VencError("x264: failed to initialize encoder (no HIP device or bad parameters)")
+        self.pic_in, self.pic_out = X264Picture(), X264Picture()
+        if self.L.x264_picture_alloc(C.byref(self.pic_in), X264_CSP_I420, width, height) != 0:
+            raise VencError("x264: could not allocate input picture")
+        self.width, self.height = width, height
+        self._planes = [np.ctypeslib.as_array(self.pic_in.img.plane[0], (height, width)),
+                        np.ctypeslib.as_array(self.pic_in.img.plane[1], (height // 2, width // 2)),
+                        np.ctypeslib.as_array(self.pic_in.img.plane[2], (height // 2, width // 2))]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.x264_picture_clean(C.byref(self.pic_in))
+            self.L.x264_encoder_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _collect(self, size, nals, n):
+        base = C.addressof(nals[0].p_payload.contents)
+        payload = C.string_at(base, size)
+        lst = [(nals[i].i_type, nals[i].i_ref_idc, C.addressof(nals[i].p_payload.contents) - base, nals[i].i_payload)
+               for i in range(n)]
+        return EncodedFrame(payload, lst, self.pic_out.i_pts, self.pic_out.i_dts, bool(self.pic_out.b_keyframe))
+
+    def encode(self, y, u, v, pts):
+        """One call of x264_encoder_encode(); returns an EncodedFrame or None (frame buffered)."""
+        self.pic_in.i_type = X264_TYPE_AUTO
+        self.pic_in.i_pts = pts
+        np.copyto(self._planes[0], y)
+        np.copyto(self._planes[1], u)
+        np.copyto(self._planes[2], v)
+        nals, n = C.POINTER(X264Nal)(), C.c_int(0)
+        size = self.L.x264_encoder_encode(self.h, C.byref(nals), C.byref(n), C.byref(self.pic_in),
+                                          C.byref(self.pic_out))
+        if size < 0:
+            raise VencError("x264: encoder error")
+        return self._collect(size, nals, n.value) if size > 0 else None
+
+    def delayed_frames(self):
+        return self.L.x264_encoder_delayed_frames(self.h)
+
+    def flush(self):
+        """The reference's drain loop (av_encode.c:1076-1083)."""
+        out = []
+        while self.delayed_frames() > 0:
+            nals, n = C.POINTER(X264Nal)(), C.c_int(0)
+            size = self.L.x264_encoder_encode(self.h, C.byref(nals), C.byref(n), None, C.byref(self.pic_out))
+            if size < 0:
+                raise VencError("x264: encoder error")
+            if size > 0:
+                out.append(self._collect(size, nals, n.value))
+        return out
+
+    def encode_resident(self, dev_ptr, frame_stride, n_frames, sink=None, first_pts=0):
+        """Encode frames already in HBM; sink(payload_bytes, nal_list, pts, keyframe) per frame, or count only."""
+        def _cb(user, nals, n, size, pic):
+            if sink is not None:
+                base = C.addressof(nals[0].p_payload.contents)
+                lst = [(nals[i].i_type, nals[i].i_ref_idc, C.addressof(nals[i].p_payload.contents) - base,
+                        nals[i].i_payload) for i in range(n)]
+                sink(C.string_at(base, size), lst, pic.contents.i_pts, bool(pic.contents.b_keyframe))
+            return 0
+        cb = SINK_FN(_cb)
+        r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts, cb, None)
+        if r < 0:
+            raise VencError("x264_venc_encode_resident failed: %s" % hip_lib().venc_last_error().decode())
+        return r

@@ -1,0 +1,90 @@
+/*
+ * hostcheck.cpp -- g++ build of the per-lane device functions (venc_device.h)
+ * and the synthetic source for CPU-only tests.  TEST ARTEFACT: nothing in the
+ * product loads this library; it exists so the lane-level logic that runs on
+ * the GPU can be checked against the oracle in a container without a GPU.
+ */
+#include <string.h>
+
+#include "venc_device.h"
+#include "venc_synth.h"
+
+extern "C" {
+
+void hc_fill_qparams(venc_qparams *q, int qp) {
+    q->per = qp / 6;
+    q->qbits = 15 + qp / 6;
+    for (int k = 0; k < 3; k++) {
+        q->mf[k] = venc_mf[(qp % 6) * 3 + k];
+        q->v[k] = venc_v[(qp % 6) * 3 + k];
+    }
+    q->f_intra = (1 << q->qbits) / 3;
+    q->f_inter = (1 << q->qbits) / 6;
+}
+int hc_chroma_qp(int qp) { return qp < 30 ? qp : venc_qpc_hi[qp - 30]; }
+
+void hc_fdct4(const int *x, int *w) { venc_fdct4(x, w); }
+void hc_idct4(const int *d, int *r) { venc_idct4(d, r); }
+int hc_quant(int w, int qp, int r, int intra) {
+    venc_qparams q;
+    hc_fill_qparams(&q, qp);
+    return venc_quant(w, &q, r, intra);
+}
+int hc_dequant(int lv, int qp, int r) {
+    venc_qparams q;
+    hc_fill_qparams(&q, qp);
+    return venc_dequant(lv, &q, r);
+}
+int hc_zigzag(int i) { return venc_zigzag_ct(i); }
+
+/* CAVLC block into a byte buffer (MSB first); returns bit count */
+int hc_cavlc_block(const int *c, int first, int max_coef, int nC, unsigned char *out, int cap_bytes) {
+    uint32_t words[32];
+    venc_bitsink b;
+    venc_bs_init(&b, words);
+    venc_cavlc_block(&b, c, first, max_coef, nC);
+    int bits = venc_bs_flush(&b);
+    int nb = (bits + 7) / 8;
+    if (nb > cap_bytes) return -1;
+    for (int i = 0; i < nb; i++) out[i] = (unsigned char)(words[i >> 2] >> (24 - 8 * (i & 3)));
+    return bits;
+}
+int hc_ue_bits(unsigned v, unsigned char *out) {
+    uint32_t words[4];
+    venc_bitsink b;
+    venc_bs_init(&b, words);
+    venc_bs_ue(&b, v);
+    int bits = venc_bs_flush(&b);
+    for (int i = 0; i < (bits + 7) / 8; i++) out[i] = (unsigned char)(words[i >> 2] >> (24 - 8 * (i & 3)));
+    return bits;
+}
+int hc_se_bits(int v, unsigned char *out) {
+    uint32_t words[4];
+    venc_bitsink b;
+    venc_bs_init(&b, words);
+    venc_bs_se(&b, v);
+    int bits = venc_bs_flush(&b);
+    for (int i = 0; i < (bits + 7) / 8; i++) out[i] = (unsigned char)(words[i >> 2] >> (24 - 8 * (i & 3)));
+    return bits;
+}
+/* raw packed VLC tables for the structural test: which 0 coeff_token(272), 1 cdc(20),
+ * 2 total_zeros(240), 3 tz cdc(12), 4 run_before(112) */
+int hc_table(int which, unsigned short *out) {
+    const uint16_t *t;
+    int n;
+    switch (which) {
+        case 0: t = venc_vlc_coeff_token, n = 272; break;
+        case 1: t = venc_vlc_coeff_token_cdc, n = 20; break;
+        case 2: t = venc_vlc_total_zeros, n = 240; break;
+        case 3: t = venc_vlc_total_zeros_cdc, n = 12; break;
+        case 4: t = venc_vlc_run_before, n = 112; break;
+        default: return -1;
+    }
+    memcpy(out, t, n * sizeof(uint16_t));
+    return n;
+}
+int hc_cbp_code(int cbp) { return venc_cbp_inter_code[cbp]; }
+unsigned char hc_synth_pixel(int plane, int x, int y, int t, int w, int h, unsigned seed) {
+    return venc_synth_pixel(plane, x, y, t, w, h, seed);
+}
+}

@@ -1,0 +1,273 @@
+/*
+ * venc_device.h -- per-lane building blocks of the HIP macroblock path.
+ *
+ * Everything here is pure per-lane integer arithmetic (no cross-lane traffic,
+ * no memory beyond the lane's own bit sink), so the same source is compiled
+ *   - by hipcc for gfx950 into the kernels of venc_kernels.hip, and
+ *   - by g++ into the host-check library used by the "not gpu" tests
+ *     (tests/test_device_functions_cpu.py), which is how the per-lane logic is
+ *     verified in a container that has no GPU.  The host-check build is a test
+ *     artefact; the product never runs it (the product path fails loudly when
+ *     the HIP library is missing).
+ *
+ * Stages restated (reference: everything behind x264_encoder_encode(),
+ * av_encode.c:970; no reference source exists):
+ *   a4.2 forward 4x4 integer core transform ("DCT")
+ *   a4.3 scalar quantisation at fixed QP (+ Hadamard DC paths)
+ *   a4.4 zig-zag + run/level = CAVLC residual block
+ *   a4.5 dequantisation + inverse transform (reconstruction)
+ */
+#ifndef VENC_DEVICE_H
+#define VENC_DEVICE_H
+#include <stdint.h>
+
+#include "venc_tables.h"
+
+#if defined(__HIPCC__)
+#define VENC_DEV __device__ __forceinline__
+#else
+#define VENC_DEV static inline
+#endif
+
+/* quantiser constants of one QP, computed on the host once per encoder */
+typedef struct {
+    int per;   /* qp / 6 */
+    int qbits; /* 15 + qp/6 */
+    int mf[3]; /* MF[qp%6][class] */
+    int v[3];  /* V[qp%6][class] */
+    int f_intra, f_inter;
+} venc_qparams;
+
+/* zig-zag scan index -> raster index as a foldable expression (keeps unrolled
+ * loops free of table loads so coefficient arrays stay in registers) */
+VENC_DEV int venc_zigzag_ct(int i) { return (int)((0xFEB7ADC963258410ull >> (4 * i)) & 15ull); }
+
+VENC_DEV int venc_pos_class(int r) {
+    int row = r >> 2, col = r & 3;
+    return (!(row & 1) && !(col & 1)) ? 0 : ((row & 1) && (col & 1)) ? 1 : 2;
+}
+
+/* ---------------------------------------------------------------- transforms */
+VENC_DEV void venc_fdct4(const int x[16], int w[16]) {
+    int t[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int s0 = x[4 * i] + x[4 * i + 3], s1 = x[4 * i + 1] + x[4 * i + 2];
+        int d0 = x[4 * i] - x[4 * i + 3], d1 = x[4 * i + 1] - x[4 * i + 2];
+        t[4 * i] = s0 + s1;
+        t[4 * i + 1] = 2 * d0 + d1;
+        t[4 * i + 2] = s0 - s1;
+        t[4 * i + 3] = d0 - 2 * d1;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int s0 = t[j] + t[12 + j], s1 = t[4 + j] + t[8 + j];
+        int d0 = t[j] - t[12 + j], d1 = t[4 + j] - t[8 + j];
+        w[j] = s0 + s1;
+        w[4 + j] = 2 * d0 + d1;
+        w[8 + j] = s0 - s1;
+        w[12 + j] = d0 - 2 * d1;
+    }
+}
+/* inverse core transform incl. the final (x + 32) >> 6; rows first (8.5.12.2) */
+VENC_DEV void venc_idct4(const int d[16], int r[16]) {
+    int f[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[4 * i] + d[4 * i + 2], e1 = d[4 * i] - d[4 * i + 2];
+        int e2 = (d[4 * i + 1] >> 1) - d[4 * i + 3], e3 = d[4 * i + 1] + (d[4 * i + 3] >> 1);
+        f[4 * i] = e0 + e3;
+        f[4 * i + 1] = e1 + e2;
+        f[4 * i + 2] = e1 - e2;
+        f[4 * i + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = f[j] + f[8 + j], g1 = f[j] - f[8 + j];
+        int g2 = (f[4 + j] >> 1) - f[12 + j], g3 = f[4 + j] + (f[12 + j] >> 1);
+        r[j] = (g0 + g3 + 32) >> 6;
+        r[4 + j] = (g1 + g2 + 32) >> 6;
+        r[8 + j] = (g1 - g2 + 32) >> 6;
+        r[12 + j] = (g0 - g3 + 32) >> 6;
+    }
+}
+
+/* ---------------------------------------------------------------- quantiser */
+VENC_DEV int venc_quant_mag(int w, int mf, int f, int shift) {
+    unsigned a = (unsigned)(w < 0 ? -w : w);
+    int lv = (int)((a * (unsigned)mf + (unsigned)f) >> shift);
+    return w < 0 ? -lv : lv;
+}
+/* AC / normal coefficient at raster position r */
+VENC_DEV int venc_quant(int w, const venc_qparams *q, int r, int intra) {
+    return venc_quant_mag(w, q->mf[venc_pos_class(r)], intra ? q->f_intra : q->f_inter, q->qbits);
+}
+VENC_DEV int venc_dequant(int lv, const venc_qparams *q, int r) { return (lv * q->v[venc_pos_class(r)]) << q->per; }
+/* Intra16x16 luma DC on the un-halved 4x4 Hadamard output */
+VENC_DEV int venc_quant_luma_dc(int y, const venc_qparams *q) {
+    return venc_quant_mag(y, q->mf[0], 4 * q->f_intra, q->qbits + 2);
+}
+VENC_DEV int venc_dequant_luma_dc(int f, const venc_qparams *q) {
+    int ls = 16 * q->v[0];
+    if (q->per >= 6) return (f * ls) << (q->per - 6);
+    return (f * ls + (1 << (5 - q->per))) >> (6 - q->per);
+}
+VENC_DEV int venc_quant_chroma_dc(int y, const venc_qparams *q, int intra) {
+    return venc_quant_mag(y, q->mf[0], 2 * (intra ? q->f_intra : q->f_inter), q->qbits + 1);
+}
+VENC_DEV int venc_dequant_chroma_dc(int f, const venc_qparams *q) { return ((f * 16 * q->v[0]) << q->per) >> 5; }
+
+/* ---------------------------------------------------------------- bit sink */
+/* MSB-first 32-bit words into lane-private memory */
+typedef struct {
+    uint32_t *w;
+    uint64_t acc;
+    int nacc;   /* valid low bits in acc, < 32 between calls */
+    int nwords; /* complete words stored */
+} venc_bitsink;
+
+VENC_DEV void venc_bs_init(venc_bitsink *b, uint32_t *w) {
+    b->w = w;
+    b->acc = 0;
+    b->nacc = 0;
+    b->nwords = 0;
+}
+VENC_DEV void venc_bs_put(venc_bitsink *b, uint32_t code, int len) { /* 0 <= len <= 32, code < 2^len */
+    b->acc = (b->acc << len) | (uint64_t)code;
+    b->nacc += len;
+    if (b->nacc >= 32) {
+        b->w[b->nwords++] = (uint32_t)(b->acc >> (b->nacc - 32));
+        b->nacc -= 32;
+    }
+}
+VENC_DEV int venc_bs_bits(const venc_bitsink *b) { return 32 * b->nwords + b->nacc; }
+/* store the partial last word left-aligned; returns total bits */
+VENC_DEV int venc_bs_flush(venc_bitsink *b) {
+    if (b->nacc > 0) b->w[b->nwords] = (uint32_t)(b->acc << (32 - b->nacc));
+    return venc_bs_bits(b);
+}
+VENC_DEV int venc_ilog2(uint32_t v) { /* floor(log2(v)), v > 0 */
+#if defined(__HIPCC__)
+    return 31 - __clz((int)v);
+#else
+    return 31 - __builtin_clz(v);
+#endif
+}
+VENC_DEV int venc_popc(uint32_t v) {
+#if defined(__HIPCC__)
+    return __popc(v);
+#else
+    return __builtin_popcount(v);
+#endif
+}
+VENC_DEV void venc_bs_ue(venc_bitsink *b, uint32_t v) {
+    int k = venc_ilog2(v + 1);
+    venc_bs_put(b, v + 1, 2 * k + 1); /* k zeros followed by the (k+1)-bit value */
+}
+VENC_DEV void venc_bs_se(venc_bitsink *b, int v) { venc_bs_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+
+/* ---------------------------------------------------------------- CAVLC block
+ * c[]: the block's levels in scan order; the block occupies scan positions
+ * first .. first+max_coef-1 of c[] (first = 1, max_coef = 15 for AC-only blocks).
+ * nC < 0 selects the chroma-DC tables.  All loops over c[] are fully unrolled so
+ * that c[] stays in registers.  Returns TotalCoeff. */
+VENC_DEV int venc_cavlc_block(venc_bitsink *b, const int c[16], int first, int max_coef, int nC) {
+    uint32_t nz = 0, ones = 0, neg = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int k = i - first;
+        if (k >= 0 && k < max_coef) {
+            int v = c[i];
+            nz |= (uint32_t)(v != 0) << k;
+            ones |= (uint32_t)(v == 1 || v == -1) << k;
+            neg |= (uint32_t)(v < 0) << k;
+        }
+    }
+    int total = venc_popc(nz);
+    /* trailing ones: up to three +-1 at the high-frequency end */
+    int t1 = 0;
+    uint32_t m = nz;
+    for (int k = 0; k < 3 && m; k++) {
+        int i = venc_ilog2(m);
+        if (!((ones >> i) & 1)) break;
+        t1++;
+        m ^= 1u << i;
+    }
+    uint32_t tok;
+    if (nC < 0)
+        tok = venc_vlc_coeff_token_cdc[4 * total + t1];
+    else
+        tok = venc_vlc_coeff_token[(nC < 2 ? 0 : nC < 4 ? 68 : nC < 8 ? 136 : 204) + 4 * total + t1];
+    venc_bs_put(b, tok & 0xff, (int)(tok >> 8));
+    if (total == 0) return 0;
+    {
+        uint32_t mm = nz;
+        for (int k = 0; k < t1; k++) {
+            int i = venc_ilog2(mm);
+            venc_bs_put(b, (neg >> i) & 1, 1);
+            mm ^= 1u << i;
+        }
+    }
+    /* remaining levels, high frequency first (m has the trailing ones removed) */
+    int sl = (total > 10 && t1 < 3) ? 1 : 0;
+    int first_level = 1;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        int k = i - first;
+        if (k >= 0 && k < max_coef && ((m >> k) & 1)) {
+            int lv = c[i];
+            int alv = lv < 0 ? -lv : lv;
+            int code = 2 * alv - 2 + (lv < 0);
+            if (first_level && t1 < 3) code -= 2;
+            first_level = 0;
+            if (sl == 0) {
+                if (code < 14)
+                    venc_bs_put(b, 1, code + 1);
+                else if (code < 30)
+                    venc_bs_put(b, 16u | (uint32_t)(code - 14), 19);
+                else
+                    venc_bs_put(b, 4096u | (uint32_t)(code - 30), 28);
+            } else {
+                if (code < (15 << sl))
+                    venc_bs_put(b, (1u << sl) | (uint32_t)(code & ((1 << sl) - 1)), (code >> sl) + 1 + sl);
+                else
+                    venc_bs_put(b, 4096u | (uint32_t)(code - (15 << sl)), 28);
+            }
+            if (sl == 0) sl = 1;
+            if (alv > (3 << (sl - 1)) && sl < 6) sl++;
+        }
+    }
+    int last = venc_ilog2(nz);
+    int total_zeros = last + 1 - total;
+    if (total < max_coef) {
+        uint32_t tz = (max_coef == 4) ? venc_vlc_total_zeros_cdc[4 * (total - 1) + total_zeros]
+                                      : venc_vlc_total_zeros[16 * (total - 1) + total_zeros];
+        venc_bs_put(b, tz & 0xff, (int)(tz >> 8));
+    }
+    /* run_before for every coefficient but the lowest, while zeros remain */
+    int zeros_left = total_zeros;
+    uint32_t rest = nz;
+    while (zeros_left > 0) {
+        int i = venc_ilog2(rest);
+        rest ^= 1u << i;
+        if (!rest) break;
+        int run = i - venc_ilog2(rest) - 1;
+        uint32_t rb = venc_vlc_run_before[16 * ((zeros_left > 7 ? 7 : zeros_left) - 1) + run];
+        venc_bs_put(b, rb & 0xff, (int)(rb >> 8));
+        zeros_left -= run;
+    }
+    return total;
+}
+
+/* nC from the neighbouring blocks' TotalCoeff (9.2.1) */
+VENC_DEV int venc_nc(int availA, int nA, int availB, int nB) {
+    if (availA && availB) return (nA + nB + 1) >> 1;
+    return availA ? nA : availB ? nB : 0;
+}
+VENC_DEV int venc_median3(int a, int b, int c) {
+    int mn = a < b ? a : b, mx = a < b ? b : a;
+    return c < mn ? mn : c > mx ? mx : c;
+}
+VENC_DEV int venc_clip_u8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+
+#endif

@@ -1,0 +1,469 @@
+/*
+ * venc_hip.hip -- C-ABI launcher of the gfx950 macroblock-loop engine
+ * (declared in include/venc_hip.h).  Owns device memory, the HIP stream, the
+ * pinned output pool, and the per-step kernel sequence.  No PyTorch, no
+ * third-party code: hipcc + libamdhip64 only.
+ *
+ * Reference boundary served: x264_encoder_encode() at av_encode.c:970 -- the C
+ * shim (x264_shim.c) turns each call into venc_upload + venc_encode_step and
+ * wraps the slice RBSPs produced here into the NAL array the reference's muxer
+ * consumes (av_encode.c:670-834).
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/venc_hip.h"
+#include "venc_kernels.hip"
+#include "venc_synth.h"
+
+static thread_local char g_err[512] = "";
+#define SET_ERR(...) snprintf(g_err, sizeof(g_err), __VA_ARGS__)
+#define HIP_OK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            SET_ERR("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            if (getenv("VENC_DEBUG")) fprintf(stderr, "venc: %s\n", g_err);                   \
+            return -1;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+#define VENC_EVENTS 256
+
+struct venc_ctx {
+    venc_config cfg;
+    venc_geom g;
+    venc_bufs b;
+    hipStream_t stream;
+    hipEvent_t ev[VENC_EVENTS];
+    int ev_next;
+    int parity;
+    uint8_t *d_in;        /* internal input pool (may be null) */
+    int in_frames;        /* frames addressable through b.in_base */
+    uint8_t *h_out;       /* pinned output pool (host view) */
+    venc_slice_out *d_slice;
+    int *d_slice_rows;
+    uint8_t *d_row_slice;
+    uint16_t *d_rank, *d_cand;
+    int intra_waves;
+    int steps_done;
+};
+
+/* host copies of the small quantiser tables (device copies live in venc_tables.h) */
+static const int h_mf[6][3] = {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554},
+                               {9362, 3647, 5825},  {8192, 3355, 5243},  {7282, 2893, 4559}};
+static const int h_v[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16}, {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+static const int h_qpc_hi[22] = {29, 30, 31, 32, 32, 33, 34, 34, 35, 35, 36, 36, 37, 37, 37, 38, 38, 38, 39, 39, 39, 39};
+
+static void fill_qparams(venc_qparams *q, int qp) {
+    q->per = qp / 6;
+    q->qbits = 15 + qp / 6;
+    for (int k = 0; k < 3; k++) {
+        q->mf[k] = h_mf[qp % 6][k];
+        q->v[k] = h_v[qp % 6][k];
+    }
+    q->f_intra = (1 << q->qbits) / 3;
+    q->f_inter = (1 << q->qbits) / 6;
+}
+
+extern "C" int venc_abi_version(void) { return VENC_ABI_VERSION; }
+extern "C" const char *venc_last_error(void) { return g_err; }
+extern "C" int venc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" void venc_close(venc_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < VENC_EVENTS; i++)
+        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    (void)hipFree(c->d_in);
+    (void)hipFree(c->b.recon);
+    (void)hipFree(c->b.mvsad);
+    (void)hipFree(c->b.levels);
+    (void)hipFree(c->b.mbinfo);
+    (void)hipFree(c->b.mbbits);
+    (void)hipFree(c->b.mbnbits);
+    (void)hipFree(c->b.mboff);
+    (void)hipFree(c->d_slice);
+    (void)hipFree(c->d_slice_rows);
+    (void)hipFree(c->d_row_slice);
+    (void)hipFree(c->d_rank);
+    (void)hipFree(c->d_cand);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    free(c);
+}
+
+extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
+    if (!cfg || !out) {
+        SET_ERR("venc_open: null argument");
+        return -1;
+    }
+    *out = NULL;
+    if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 1) || (cfg->height & 1) || cfg->width > 16384 ||
+        cfg->height > 16384) {
+        SET_ERR("venc_open: unsupported size %dx%d", cfg->width, cfg->height);
+        return -1;
+    }
+    if (cfg->qp < 12 || cfg->qp > 51) {
+        SET_ERR("venc_open: qp %d outside 12..51", cfg->qp);
+        return -1;
+    }
+    if (cfg->max_items < 1 || cfg->max_items > VENC_MAX_ITEMS || cfg->out_slots < 1 || cfg->in_slots < 0) {
+        SET_ERR("venc_open: bad pool configuration");
+        return -1;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        SET_ERR("venc_open: no HIP device available (the HIP path has no CPU fallback)");
+        return -2;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) {
+        SET_ERR("venc_open: device %d out of range (%d devices)", cfg->device, ndev);
+        return -1;
+    }
+    HIP_OK(hipSetDevice(cfg->device));
+    venc_ctx *c = (venc_ctx *)calloc(1, sizeof(venc_ctx));
+    if (!c) return -1;
+    c->cfg = *cfg;
+    venc_geom &g = c->g;
+    g.w = cfg->width;
+    g.h = cfg->height;
+    g.mbw = (g.w + 15) / 16;
+    g.mbh = (g.h + 15) / 16;
+    g.cw = g.mbw * 16;
+    g.ch = g.mbh * 16;
+    g.nmb = g.mbw * g.mbh;
+    g.n_slices = cfg->n_slices < 1 ? 1 : cfg->n_slices;
+    if (g.n_slices > g.mbh) g.n_slices = g.mbh;
+    if (g.n_slices > VENC_MAX_SLICES) g.n_slices = VENC_MAX_SLICES;
+    g.qp = cfg->qp;
+    fill_qparams(&g.ql, cfg->qp);
+    fill_qparams(&g.qc, cfg->qp < 30 ? cfg->qp : h_qpc_hi[cfg->qp - 30]);
+    c->cfg.n_slices = g.n_slices;
+
+#define OPEN_OK(call)               \
+    do {                            \
+        hipError_t e_ = (call);     \
+        if (e_ != hipSuccess) {     \
+            SET_ERR("%s failed: %s", #call, hipGetErrorString(e_)); \
+            venc_close(c);          \
+            return -1;              \
+        }                           \
+    } while (0)
+
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (int i = 0; i < VENC_EVENTS; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+
+    /* slice bands: the first (mbh % n) bands get one extra MB row */
+    int rows[VENC_MAX_SLICES + 1];
+    uint8_t *row_slice = (uint8_t *)malloc((size_t)g.mbh);
+    int maxrows = 0;
+    {
+        int base = g.mbh / g.n_slices, rem = g.mbh % g.n_slices, r = 0;
+        for (int s = 0; s < g.n_slices; s++) {
+            rows[s] = r;
+            int n = base + (s < rem ? 1 : 0);
+            for (int k = 0; k < n; k++) row_slice[r + k] = (uint8_t)s;
+            if (n > maxrows) maxrows = n;
+            r += n;
+        }
+        rows[g.n_slices] = r;
+    }
+    c->intra_waves = maxrows < INTRA_MAX_WAVES ? maxrows : INTRA_MAX_WAVES;
+    OPEN_OK(hipMalloc(&c->d_slice_rows, sizeof(int) * (g.n_slices + 1)));
+    OPEN_OK(hipMemcpy(c->d_slice_rows, rows, sizeof(int) * (g.n_slices + 1), hipMemcpyHostToDevice));
+    OPEN_OK(hipMalloc(&c->d_row_slice, (size_t)g.mbh));
+    OPEN_OK(hipMemcpy(c->d_row_slice, row_slice, (size_t)g.mbh, hipMemcpyHostToDevice));
+    free(row_slice);
+
+    /* ME tie-break order: all 33x33 displacements sorted by (|dx|+|dy|, dy, dx) */
+    {
+        uint16_t rank[VENC_ME_CANDS], cand[VENC_ME_CANDS];
+        int r = 0;
+        for (int l1 = 0; l1 <= 2 * VENC_ME_RANGE; l1++)
+            for (int dy = -VENC_ME_RANGE; dy <= VENC_ME_RANGE; dy++)
+                for (int dx = -VENC_ME_RANGE; dx <= VENC_ME_RANGE; dx++)
+                    if (abs(dx) + abs(dy) == l1) {
+                        rank[(dy + 16) * 33 + dx + 16] = (uint16_t)r;
+                        cand[r] = (uint16_t)(((dy + 16) << 8) | (dx + 16));
+                        r++;
+                    }
+        OPEN_OK(hipMalloc(&c->d_rank, sizeof(rank)));
+        OPEN_OK(hipMemcpy(c->d_rank, rank, sizeof(rank), hipMemcpyHostToDevice));
+        OPEN_OK(hipMalloc(&c->d_cand, sizeof(cand)));
+        OPEN_OK(hipMemcpy(c->d_cand, cand, sizeof(cand), hipMemcpyHostToDevice));
+    }
+
+    venc_bufs &b = c->b;
+    const size_t G = (size_t)cfg->max_items, nmb = (size_t)g.nmb;
+    b.max_items = cfg->max_items;
+    b.in_frame_stride = (size_t)g.w * g.h * 3 / 2;
+    if (cfg->in_slots > 0) {
+        OPEN_OK(hipMalloc(&c->d_in, b.in_frame_stride * cfg->in_slots));
+        b.in_base = c->d_in;
+        c->in_frames = cfg->in_slots;
+    }
+    b.recon_frame_bytes = (size_t)g.cw * g.ch * 3 / 2;
+    OPEN_OK(hipMalloc(&b.recon, 2 * G * b.recon_frame_bytes));
+    OPEN_OK(hipMemset(b.recon, 128, 2 * G * b.recon_frame_bytes));
+    OPEN_OK(hipMalloc(&b.mvsad, G * nmb * 4));
+    OPEN_OK(hipMemset(b.mvsad, 0, G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.levels, G * nmb * VENC_MB_COEFS * 2));
+    OPEN_OK(hipMalloc(&b.mbinfo, G * nmb * sizeof(venc_mbinfo)));
+    OPEN_OK(hipMemset(b.mbinfo, 0, G * nmb * sizeof(venc_mbinfo)));
+    OPEN_OK(hipMalloc(&b.mbbits, G * nmb * VENC_MB_WORDS * 4));
+    OPEN_OK(hipMalloc(&b.mbnbits, G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
+    OPEN_OK(hipMalloc(&c->d_slice, G * g.n_slices * sizeof(venc_slice_out)));
+    b.slice_first_row = c->d_slice_rows;
+    b.row_slice = c->d_row_slice;
+    b.me_rank = c->d_rank;
+    b.me_cand = c->d_cand;
+
+    /* pinned, device-mapped output pool: header | slice table | data */
+    b.out_data_off = (uint32_t)((sizeof(venc_out_header) + (size_t)g.n_slices * sizeof(venc_slice_out) + 63) & ~(size_t)63);
+    b.out_cap = (uint32_t)((size_t)g.cw * g.ch + 65536);
+    b.out_slot_bytes = ((size_t)b.out_data_off + b.out_cap + 255) & ~(size_t)255;
+    OPEN_OK(hipHostMalloc((void **)&c->h_out, b.out_slot_bytes * cfg->out_slots, hipHostMallocMapped));
+    memset(c->h_out, 0, b.out_slot_bytes * cfg->out_slots);
+    void *dview = NULL;
+    OPEN_OK(hipHostGetDevicePointer(&dview, c->h_out, 0));
+    b.out_base = (uint8_t *)dview;
+    OPEN_OK(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+extern "C" int venc_mb_width(const venc_ctx *c) { return c->g.mbw; }
+extern "C" int venc_mb_height(const venc_ctx *c) { return c->g.mbh; }
+extern "C" int venc_n_slices(const venc_ctx *c) { return c->g.n_slices; }
+extern "C" size_t venc_frame_bytes(const venc_ctx *c) { return c->b.in_frame_stride; }
+
+extern "C" void *venc_host_alloc(size_t bytes) {
+    void *p = NULL;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return NULL;
+    return p;
+}
+extern "C" void venc_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+extern "C" void *venc_input_slot_ptr(venc_ctx *c, int slot) {
+    if (!c->d_in || slot < 0 || slot >= c->cfg.in_slots) return NULL;
+    return c->d_in + (size_t)slot * c->b.in_frame_stride;
+}
+
+extern "C" int venc_set_input(venc_ctx *c, const void *d_frames, size_t frame_stride, int n_frames) {
+    if (!d_frames || n_frames < 1 || frame_stride < (size_t)c->g.w * c->g.h * 3 / 2) {
+        SET_ERR("venc_set_input: bad arguments");
+        return -1;
+    }
+    c->b.in_base = (const uint8_t *)d_frames;
+    c->b.in_frame_stride = frame_stride;
+    c->in_frames = n_frames;
+    return 0;
+}
+
+extern "C" int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int sy, const uint8_t *u, int su, const uint8_t *v,
+                           int sv) {
+    if (!c->d_in || c->b.in_base != c->d_in || slot < 0 || slot >= c->cfg.in_slots) {
+        SET_ERR("venc_upload: slot %d not in the internal pool", slot);
+        return -1;
+    }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    const int w = c->g.w, h = c->g.h;
+    uint8_t *d = c->d_in + (size_t)slot * c->b.in_frame_stride;
+    HIP_OK(hipMemcpy2DAsync(d, (size_t)w, y, (size_t)sy, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpy2DAsync(d + (size_t)w * h, (size_t)(w / 2), u, (size_t)su, (size_t)(w / 2), (size_t)(h / 2),
+                            hipMemcpyHostToDevice, c->stream));
+    HIP_OK(hipMemcpy2DAsync(d + (size_t)w * h * 5 / 4, (size_t)(w / 2), v, (size_t)sv, (size_t)(w / 2), (size_t)(h / 2),
+                            hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+extern "C" int venc_upload_sync(venc_ctx *c) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, const int *out_slots, int is_idr,
+                                int frame_num, const int *idr_ids) {
+    if (n_items < 1 || n_items > c->cfg.max_items || !in_slots || !out_slots) {
+        SET_ERR("venc_encode_step: n_items %d outside 1..%d", n_items, c->cfg.max_items);
+        return -1;
+    }
+    if (!c->b.in_base) {
+        SET_ERR("venc_encode_step: no input pool (in_slots = 0 and venc_set_input not called)");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    venc_step S;
+    memset(&S, 0, sizeof(S));
+    S.n_items = n_items;
+    S.is_idr = is_idr ? 1 : 0;
+    S.frame_num = frame_num;
+    S.parity = c->parity;
+    for (int i = 0; i < n_items; i++) {
+        if (in_slots[i] < 0 || in_slots[i] >= c->in_frames || out_slots[i] < 0 || out_slots[i] >= c->cfg.out_slots) {
+            SET_ERR("venc_encode_step: slot out of range (item %d: in %d, out %d)", i, in_slots[i], out_slots[i]);
+            return -1;
+        }
+        S.in_slot[i] = in_slots[i];
+        S.out_slot[i] = out_slots[i];
+        S.idr_id[i] = idr_ids ? idr_ids[i] : 0;
+    }
+    const venc_geom &g = c->g;
+    const venc_bufs &b = c->b;
+    if (is_idr) {
+        hipLaunchKernelGGL(k_intra, dim3(g.n_slices, 1, n_items), dim3(64 * c->intra_waves), 0, c->stream, g, b, S);
+    } else {
+        hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
+        hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, c->stream, g, b, S);
+    }
+    hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, c->stream, g, b, S);
+    hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, c->stream, g, b, S, c->d_slice);
+    hipLaunchKernelGGL(k_pack, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, c->stream, g, b, S,
+                       (const venc_slice_out *)c->d_slice);
+    HIP_OK(hipGetLastError());
+    c->parity ^= 1;
+    c->steps_done++;
+    return 0;
+}
+
+extern "C" int venc_mark(venc_ctx *c) {
+    const int t = c->ev_next;
+    HIP_OK(hipEventRecord(c->ev[t % VENC_EVENTS], c->stream));
+    c->ev_next++;
+    return t;
+}
+extern "C" int venc_wait(venc_ctx *c, int ticket) {
+    if (ticket < 0 || ticket >= c->ev_next || c->ev_next - ticket > VENC_EVENTS) {
+        SET_ERR("venc_wait: stale ticket %d", ticket);
+        return -1;
+    }
+    HIP_OK(hipEventSynchronize(c->ev[ticket % VENC_EVENTS]));
+    return 0;
+}
+extern "C" int venc_sync(venc_ctx *c) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int venc_get_frame(venc_ctx *c, int slot, venc_frame *out) {
+    if (slot < 0 || slot >= c->cfg.out_slots || !out) {
+        SET_ERR("venc_get_frame: bad slot %d", slot);
+        return -1;
+    }
+    const uint8_t *p = c->h_out + (size_t)slot * c->b.out_slot_bytes;
+    const venc_out_header *h = (const venc_out_header *)p;
+    out->data = p + c->b.out_data_off;
+    out->slices = (const venc_slice *)(p + sizeof(venc_out_header));
+    out->n_slices = h->n_slices;
+    out->total_bytes = h->total_bytes;
+    out->error = h->error;
+    if (h->error) {
+        SET_ERR("venc_get_frame: output capacity exceeded in slot %d", slot);
+        return -3;
+    }
+    return 0;
+}
+
+extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_t dst_bytes) {
+    if (item < 0 || item >= c->cfg.max_items || !dst) {
+        SET_ERR("venc_debug_read: bad item");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    const venc_geom &g = c->g;
+    const size_t nmb = (size_t)g.nmb;
+    const void *src = NULL;
+    size_t n = 0;
+    const int last_parity = c->parity ^ 1;
+    const uint8_t *rec = c->b.recon + (size_t)(last_parity * c->b.max_items + item) * c->b.recon_frame_bytes;
+    switch (what) {
+        case 0: src = c->b.mvsad + item * nmb, n = nmb * 4; break;
+        case 1: src = c->b.levels + item * nmb * VENC_MB_COEFS, n = nmb * VENC_MB_COEFS * 2; break;
+        case 2: src = c->b.mbinfo + item * nmb, n = nmb * sizeof(venc_mbinfo); break;
+        case 3: src = c->b.mbnbits + item * nmb, n = nmb * 4; break;
+        case 4: src = rec, n = (size_t)g.cw * g.ch; break;
+        case 5: src = rec + (size_t)g.cw * g.ch, n = (size_t)g.cw * g.ch / 4; break;
+        case 6: src = rec + (size_t)g.cw * g.ch * 5 / 4, n = (size_t)g.cw * g.ch / 4; break;
+        case 7: src = c->b.mboff + item * nmb, n = nmb * 4; break;
+        default: SET_ERR("venc_debug_read: unknown selector %d", what); return -1;
+    }
+    if (dst_bytes < n) {
+        SET_ERR("venc_debug_read: destination too small (%zu < %zu)", dst_bytes, n);
+        return -1;
+    }
+    HIP_OK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int venc_time_kernel(venc_ctx *c, int which, int n_items, int iters, float *ms_per_launch) {
+    (void)c;
+    (void)which;
+    (void)n_items;
+    (void)iters;
+    (void)ms_per_launch;
+    SET_ERR("venc_time_kernel: not implemented in this build");
+    return -1;
+}
+
+/* ------------------------------------------------------------------ synthetic source */
+extern "C" void venc_synth_frame(int width, int height, int frame_index, uint32_t seed, uint8_t *y, uint8_t *u,
+                                 uint8_t *v) {
+    for (int r = 0; r < height; r++)
+        for (int x = 0; x < width; x++) y[(size_t)r * width + x] = venc_synth_pixel(0, x, r, frame_index, width, height, seed);
+    const int cw = width / 2, chh = height / 2;
+    for (int r = 0; r < chh; r++)
+        for (int x = 0; x < cw; x++) {
+            u[(size_t)r * cw + x] = venc_synth_pixel(1, x, r, frame_index, width, height, seed);
+            v[(size_t)r * cw + x] = venc_synth_pixel(2, x, r, frame_index, width, height, seed);
+        }
+}
+
+__global__ void k_synth(uint8_t *frames, size_t frame_stride, int w, int h, int first_frame, uint32_t seed) {
+    const int f = blockIdx.z;
+    uint8_t *base = frames + (size_t)f * frame_stride;
+    const size_t ysz = (size_t)w * h;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = ysz * 3 / 2;
+    if (i >= total) return;
+    int plane, x, y;
+    if (i < ysz) {
+        plane = 0, x = (int)(i % w), y = (int)(i / w);
+    } else {
+        size_t j = i - ysz;
+        plane = j < ysz / 4 ? 1 : 2;
+        if (plane == 2) j -= ysz / 4;
+        x = (int)(j % (w / 2)), y = (int)(j / (w / 2));
+    }
+    base[i] = venc_synth_pixel(plane, x, y, first_frame + f, w, h, seed);
+}
+
+/* fills n_frames consecutive I420 frames in device memory with the synthetic source */
+extern "C" int venc_synth_device(void *d_frames, size_t frame_stride, int width, int height, int first_frame,
+                                 int n_frames, uint32_t seed) {
+    if (!d_frames || n_frames < 1) {
+        SET_ERR("venc_synth_device: bad arguments");
+        return -1;
+    }
+    const size_t total = (size_t)width * height * 3 / 2;
+    for (int f0 = 0; f0 < n_frames; f0 += 65535) {
+        const int nf = n_frames - f0 < 65535 ? n_frames - f0 : 65535;
+        hipLaunchKernelGGL(k_synth, dim3((unsigned)((total + 255) / 256), 1, nf), dim3(256), 0, 0,
+                           (uint8_t *)d_frames + (size_t)f0 * frame_stride, frame_stride, width, height, first_frame + f0,
+                           seed);
+    }
+    HIP_OK(hipGetLastError());
+    HIP_OK(hipDeviceSynchronize());
+    return 0;
+}

@@ -1,0 +1,92 @@
+/*
+ * venc_internal.h -- device-side data layout shared by the kernels and the
+ * launcher (venc_hip.hip).  Not part of the C-ABI (that is include/venc_hip.h).
+ *
+ * HBM layout (one encoder context, G = max items per step):
+ *   input pool    [slots][ Y w*h | U w*h/4 | V w*h/4 ]      display size, tight I420
+ *   recon         [2][G][ Y cw*ch | U | V ]                  coded size, ping-pong by frame parity
+ *   mvsad         [G][nmb] u32   = sad<<16 | (dy&255)<<8 | (dx&255)
+ *   levels        [G][nmb][27][16] i16   (block order documented in include/venc_hip.h)
+ *   mbinfo        [G][nmb] 32 B  = nnz[24] (16 luma raster, 4 Cb, 4 Cr), cbp, flags
+ *   mbbits        [G][nmb][VENC_MB_WORDS] u32  MSB-first macroblock bit strings
+ *   mbnbits/mboff [G][nmb] u32
+ *   out (pinned host, device-mapped) [out_slots][out_cap] bytes + slice table
+ */
+#ifndef VENC_INTERNAL_H
+#define VENC_INTERNAL_H
+#include <stdint.h>
+
+#include "venc_device.h"
+
+#define VENC_MAX_ITEMS 64
+#define VENC_MAX_SLICES 256
+#define VENC_MB_COEFS 432   /* 27 blocks x 16 */
+#define VENC_MB_WORDS 416   /* per-macroblock bit-string capacity: 13312 bits */
+#define VENC_LANE_WORDS 16  /* per-block private capacity: 512 bits >= 16 + 16*28 */
+#define VENC_ME_RANGE 16
+#define VENC_ME_CANDS 1089
+
+typedef struct {
+    uint8_t nnz[24];
+    uint8_t cbp;   /* bits 0-3 luma 8x8, bits 4-5 chroma (0,1,2) */
+    uint8_t flags; /* bit 0: Intra16x16 */
+    uint8_t pad[6];
+} venc_mbinfo;
+
+typedef struct {
+    uint32_t byte_off; /* offset of the slice RBSP inside the frame's output buffer (4-aligned) */
+    uint32_t nbytes;   /* RBSP bytes incl. trailing bits */
+    uint32_t nbits;    /* slice_data + header bits, without trailing */
+    uint32_t pad;
+} venc_slice_out;
+
+/* header of one output slot in pinned host memory, followed by the slice table and the data */
+typedef struct {
+    uint32_t total_bytes; /* bytes used in data[] */
+    uint32_t n_slices;
+    uint32_t error;       /* non-zero: capacity overflow */
+    uint32_t pad;
+} venc_out_header;
+
+typedef struct {
+    int w, h;        /* display */
+    int cw, ch;      /* coded */
+    int mbw, mbh, nmb;
+    int n_slices;
+    int qp;
+    venc_qparams ql, qc;
+} venc_geom;
+
+typedef struct {
+    int n_items;
+    int is_idr;
+    int frame_num;
+    int parity; /* recon buffer written this step; the other one is the reference */
+    int in_slot[VENC_MAX_ITEMS];
+    int out_slot[VENC_MAX_ITEMS];
+    int idr_id[VENC_MAX_ITEMS];
+} venc_step;
+
+typedef struct {
+    const uint8_t *in_base;
+    size_t in_frame_stride;
+    uint8_t *recon; /* [2][G] frames */
+    size_t recon_frame_bytes;
+    int max_items;
+    uint32_t *mvsad;
+    int16_t *levels;
+    venc_mbinfo *mbinfo;
+    uint32_t *mbbits;
+    uint32_t *mbnbits;
+    uint32_t *mboff;
+    const int *slice_first_row; /* n_slices + 1 */
+    const uint8_t *row_slice;   /* mbh */
+    const uint16_t *me_rank;    /* [33*33] candidate (dyi*33+dxi) -> rank */
+    const uint16_t *me_cand;    /* [1089] rank -> dyi<<8 | dxi */
+    uint8_t *out_base;          /* device view of the pinned output pool */
+    size_t out_slot_bytes;
+    uint32_t out_data_off;      /* offset of data[] inside a slot */
+    uint32_t out_cap;           /* capacity of data[] */
+} venc_bufs;
+
+#endif

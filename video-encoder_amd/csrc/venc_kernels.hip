@@ -1,0 +1,809 @@
+/*
+ * venc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the
+ * per-macroblock encode loop.  No MFMA: nothing here is a dense contraction.
+ *
+ *   k_me     a4.1  exhaustive +-16 integer-pel 16x16 SAD search, LDS-staged window
+ *   k_inter  a4.2/3/5  MC prediction, 4x4 core transform, quantisation, reconstruction (P)
+ *   k_intra  a4.2/3/5  Intra16x16-DC wavefront per slice (I)
+ *   k_cavlc  a4.4  zig-zag/run-level entropy coding, one lane per 4x4 block
+ *   k_scan   a4.4  per-slice exclusive scan of macroblock bit lengths
+ *   k_pack   a4.4  owner-gather bit packing straight into pinned host memory
+ *
+ * Row references (a4.x) are SURVEY.md section 8a; the reference has no source
+ * for any of these stages (they sit behind x264_encoder_encode(),
+ * av_encode.c:970), so the arithmetic follows spec/CODEC.md.
+ */
+#include <hip/hip_runtime.h>
+
+#include "venc_internal.h"
+
+#define DEVFN __device__ __forceinline__
+
+/* ------------------------------------------------------------------ plane addressing */
+DEVFN const uint8_t *in_plane(const venc_bufs &B, const venc_geom &g, int slot, int plane, int &stride, int &pw,
+                              int &ph) {
+    const uint8_t *base = B.in_base + (size_t)slot * B.in_frame_stride;
+    if (plane == 0) {
+        stride = g.w;
+        pw = g.w;
+        ph = g.h;
+        return base;
+    }
+    stride = g.w >> 1;
+    pw = g.w >> 1;
+    ph = g.h >> 1;
+    size_t ysz = (size_t)g.w * g.h;
+    return base + ysz + (plane == 2 ? (ysz >> 2) : 0);
+}
+DEVFN uint8_t *rec_plane(const venc_bufs &B, const venc_geom &g, int parity, int item, int plane, int &stride) {
+    uint8_t *base = B.recon + (size_t)(parity * B.max_items + item) * B.recon_frame_bytes;
+    size_t ysz = (size_t)g.cw * g.ch;
+    if (plane == 0) {
+        stride = g.cw;
+        return base;
+    }
+    stride = g.cw >> 1;
+    return base + ysz + (plane == 2 ? (ysz >> 2) : 0);
+}
+DEVFN int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+/* luma4x4BlkIdx <-> (x,y) in 4x4 units */
+DEVFN int blk_x(int b) { return (b & 1) | ((b >> 1) & 2); }
+DEVFN int blk_y(int b) { return ((b >> 1) & 1) | ((b >> 2) & 2); }
+DEVFN int blk_of(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x >> 1) << 2) | ((y >> 1) << 3); }
+
+/* ================================================================== k_me
+ * One block = 8 horizontally adjacent macroblocks of one MB row; one half-wave
+ * (32 lanes) per macroblock.  Lane l of a half-wave owns displacement column
+ * dx = l - 16 and keeps 33 accumulators (one per dy) in VGPRs.  Each of the 48
+ * window rows is fetched from LDS once per lane (5 dwords + 4 v_alignbyte) and
+ * reused for up to 16 (cur row, dy) pairs with v_sad_u8, so the inner loop is
+ * ~88 % SAD instructions.  The dx = +16 column is swept separately.  The argmin
+ * uses the total-order key (sad << 11) | rank (spec/CODEC.md section ME).
+ */
+#define ME_TILE 8
+#define ME_WDW (ME_TILE * 4 + 8) /* window row in dwords: 160 bytes */
+
+__global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_win[48 * ME_WDW];
+    __shared__ uint32_t s_cur[16 * ME_TILE * 4];
+    __shared__ uint16_t s_rank[VENC_ME_CANDS];
+
+    const int item = blockIdx.z, my = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
+    const int x0 = tx * ME_TILE * 16, y0 = my * 16;
+    int rstride;
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    int cstride, pw, ph;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+
+    for (int i = tid; i < VENC_ME_CANDS; i += 256) s_rank[i] = B.me_rank[i];
+
+    const bool xin = (x0 - 16 >= 0) && (x0 + ME_TILE * 16 + 16 <= g.cw);
+    for (int i = tid; i < 48 * ME_WDW; i += 256) {
+        int r = i / ME_WDW, d = i - r * ME_WDW;
+        int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
+        int xb = x0 - 16 + 4 * d;
+        const uint8_t *row = ref + (size_t)ry * rstride;
+        uint32_t v;
+        if (xin) {
+            v = *(const uint32_t *)(row + xb);
+        } else {
+            v = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
+                ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
+        }
+        s_win[i] = v;
+    }
+    const bool cur_fast = ((g.w & 3) == 0) && (x0 + ME_TILE * 16 <= g.w);
+    for (int i = tid; i < 16 * ME_TILE * 4; i += 256) {
+        int r = i / (ME_TILE * 4), d = i - r * (ME_TILE * 4);
+        int sy = min(y0 + r, g.h - 1);
+        int xb = x0 + 4 * d;
+        const uint8_t *row = cur + (size_t)sy * cstride;
+        uint32_t v;
+        if (cur_fast) {
+            v = *(const uint32_t *)(row + xb);
+        } else {
+            v = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
+                ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+        }
+        s_cur[i] = v;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int mbi = wave * 2 + half;
+    const int mx = tx * ME_TILE + mbi;
+
+    uint32_t c[16][4];
+#pragma unroll
+    for (int y = 0; y < 16; y++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[y][j] = s_cur[y * (ME_TILE * 4) + mbi * 4 + j];
+
+    uint32_t acc[33];
+#pragma unroll
+    for (int i = 0; i < 33; i++) acc[i] = 0;
+
+    const int boff = mbi * 16 + l32; /* window byte column of displacement dx = l32 - 16 */
+    const int dw = boff >> 2;
+    const uint32_t sh = (uint32_t)(boff & 3);
+#pragma unroll
+    for (int r = 0; r < 48; r++) {
+        const uint32_t *row = s_win + r * ME_WDW + dw;
+        uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3], d4 = row[4];
+        uint32_t r0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+        uint32_t r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        uint32_t r2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+        uint32_t r3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+#pragma unroll
+        for (int y = 0; y < 16; y++) {
+            const int dyi = r - y; /* dy + 16 */
+            if (dyi >= 0 && dyi <= 32) {
+                uint32_t a = acc[dyi];
+                a = __builtin_amdgcn_sad_u8(r0, c[y][0], a);
+                a = __builtin_amdgcn_sad_u8(r1, c[y][1], a);
+                a = __builtin_amdgcn_sad_u8(r2, c[y][2], a);
+                a = __builtin_amdgcn_sad_u8(r3, c[y][3], a);
+                acc[dyi] = a;
+            }
+        }
+    }
+    uint32_t best = 0xffffffffu;
+#pragma unroll
+    for (int dyi = 0; dyi < 33; dyi++) {
+        uint32_t key = (acc[dyi] << 11) | s_rank[dyi * 33 + l32];
+        best = min(best, key);
+    }
+    /* displacement column dx = +16 (window byte column mbi*16 + 32: dword aligned) */
+    for (int dyi = l32; dyi < 33; dyi += 32) {
+        uint32_t a = 0;
+#pragma unroll
+        for (int y = 0; y < 16; y++) {
+            const uint32_t *row = s_win + (y + dyi) * ME_WDW + mbi * 4 + 8;
+            a = __builtin_amdgcn_sad_u8(row[0], c[y][0], a);
+            a = __builtin_amdgcn_sad_u8(row[1], c[y][1], a);
+            a = __builtin_amdgcn_sad_u8(row[2], c[y][2], a);
+            a = __builtin_amdgcn_sad_u8(row[3], c[y][3], a);
+        }
+        uint32_t key = (a << 11) | s_rank[dyi * 33 + 32];
+        best = min(best, key);
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
+    if (l32 == 0 && mx < g.mbw) {
+        uint32_t cand = B.me_cand[best & 2047u];
+        int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
+        B.mvsad[(size_t)item * g.nmb + my * g.mbw + mx] =
+            ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+    }
+}
+
+/* ================================================================== macroblock transform core
+ * Lane roles inside a 32-lane macroblock team: l32 0..15 = luma4x4BlkIdx,
+ * 16..19 = Cb block k, 20..23 = Cr block k, 24..31 spare.  Every lane of the
+ * wave executes this function (the cross-lane DC exchanges use ds_bpermute).
+ */
+struct mb_lane_out {
+    int lv[16]; /* levels, scan order (index 0 zero when the DC is coded separately) */
+    int rec[16];
+    int dclv;   /* separately coded DC level owned by this lane (I16 luma / chroma) */
+    int nnz;
+};
+
+DEVFN void mb_code(int lane, bool i16, bool intra, const int cur[16], const int pred[16], const venc_geom &g,
+                   mb_lane_out &o) {
+    const int l32 = lane & 31, base = lane & 32;
+    const bool luma = l32 < 16;
+    const bool dc_sep = luma ? i16 : true;
+    const venc_qparams &q = luma ? g.ql : g.qc;
+    const int qmf0 = luma ? g.ql.mf[0] : g.qc.mf[0], qmf1 = luma ? g.ql.mf[1] : g.qc.mf[1],
+              qmf2 = luma ? g.ql.mf[2] : g.qc.mf[2];
+    const int qv0 = luma ? g.ql.v[0] : g.qc.v[0], qv1 = luma ? g.ql.v[1] : g.qc.v[1], qv2 = luma ? g.ql.v[2] : g.qc.v[2];
+    const int qbits = luma ? g.ql.qbits : g.qc.qbits, per = luma ? g.ql.per : g.qc.per;
+    const int f = intra ? (luma ? g.ql.f_intra : g.qc.f_intra) : (luma ? g.ql.f_inter : g.qc.f_inter);
+    (void)q;
+
+    int res[16], w[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) res[i] = cur[i] - pred[i];
+    venc_fdct4(res, w);
+
+    /* ---- separately coded DC: Intra16x16 luma (4x4 Hadamard over the 16 luma lanes) */
+    int oy, ox;
+    {
+        int bx = blk_x(l32 & 15), by = blk_y(l32 & 15);
+        oy = by;
+        ox = bx;
+    }
+    int ydc = 0;
+#pragma unroll
+    for (int qi = 0; qi < 16; qi++) {
+        int qy = qi >> 2, qx = qi & 3;
+        int v = __shfl(w[0], base | blk_of(qx, qy));
+        int neg = ((0xA6C0 >> (4 * oy + qy)) ^ (0xA6C0 >> (4 * ox + qx))) & 1;
+        ydc += neg ? -v : v;
+    }
+    int dcl_luma = venc_quant_luma_dc(ydc, &g.ql);
+    int fdc = 0;
+#pragma unroll
+    for (int qi = 0; qi < 16; qi++) {
+        int qy = qi >> 2, qx = qi & 3;
+        int v = __shfl(dcl_luma, base | blk_of(qx, qy));
+        int neg = ((0xA6C0 >> (4 * oy + qy)) ^ (0xA6C0 >> (4 * ox + qx))) & 1;
+        fdc += neg ? -v : v;
+    }
+    int d0_luma = venc_dequant_luma_dc(fdc, &g.ql);
+
+    /* ---- chroma DC: 2x2 over the four lanes of a plane */
+    const int cbase = base | (l32 & 28), ck = l32 & 3;
+    int yc = 0;
+#pragma unroll
+    for (int qi = 0; qi < 4; qi++) {
+        int v = __shfl(w[0], cbase | qi);
+        int neg = __popc(ck & qi) & 1;
+        yc += neg ? -v : v;
+    }
+    int dcl_chroma = venc_quant_chroma_dc(yc, &g.qc, intra);
+    int fc = 0;
+#pragma unroll
+    for (int qi = 0; qi < 4; qi++) {
+        int v = __shfl(dcl_chroma, cbase | qi);
+        int neg = __popc(ck & qi) & 1;
+        fc += neg ? -v : v;
+    }
+    int d0_chroma = venc_dequant_chroma_dc(fc, &g.qc);
+
+    /* ---- per-lane quantisation / dequantisation */
+    int d[16];
+    int nnz = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = venc_zigzag_ct(i);
+        const int cls = venc_pos_class(r);
+        const int mf = cls == 0 ? qmf0 : cls == 1 ? qmf1 : qmf2;
+        const int vv = cls == 0 ? qv0 : cls == 1 ? qv1 : qv2;
+        int l = venc_quant_mag(w[r], mf, f, qbits);
+        if (i == 0 && dc_sep) l = 0;
+        o.lv[i] = l;
+        nnz += (l != 0);
+        d[r] = (l * vv) << per;
+    }
+    if (dc_sep) d[0] = luma ? d0_luma : d0_chroma;
+    o.dclv = luma ? dcl_luma : dcl_chroma;
+    o.nnz = nnz;
+    int rr[16];
+    venc_idct4(d, rr);
+#pragma unroll
+    for (int i = 0; i < 16; i++) o.rec[i] = venc_clip_u8(pred[i] + rr[i]);
+}
+
+/* store one lane's outputs: levels, reconstruction, nnz; lane < 24 only */
+DEVFN void mb_store(int l32, bool valid, const mb_lane_out &o, int16_t *lv_mb, venc_mbinfo *info, uint8_t *rec, int rstride,
+                    int px, int py) {
+    if (!valid || l32 >= 24) return;
+    const bool luma = l32 < 16;
+    const int slot = luma ? l32 : 19 + (l32 - 16);
+    uint32_t p[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = ((uint32_t)o.lv[2 * i] & 0xffffu) | ((uint32_t)o.lv[2 * i + 1] << 16);
+    uint4 *dst = (uint4 *)(lv_mb + slot * 16);
+    dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
+    dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+    const int nidx = luma ? blk_y(l32) * 4 + blk_x(l32) : l32;
+    info->nnz[nidx] = (uint8_t)o.nnz;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t v = (uint32_t)o.rec[4 * y] | ((uint32_t)o.rec[4 * y + 1] << 8) | ((uint32_t)o.rec[4 * y + 2] << 16) |
+                     ((uint32_t)o.rec[4 * y + 3] << 24);
+        *(uint32_t *)(rec + (size_t)(py + y) * rstride + px) = v;
+    }
+}
+
+/* ================================================================== k_inter
+ * P_L0_16x16: half-wave per macroblock, 8 macroblocks per block. */
+__global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_step S) {
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int lane = tid & 63, l32 = lane & 31, base = lane & 32;
+    const int mb_raw = blockIdx.x * 8 + (tid >> 5);
+    const bool valid = mb_raw < g.nmb;
+    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const bool luma = l32 < 16;
+    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
+    const int k = l32 & 3;
+    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
+    const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
+
+    const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
+    const int dx = (int)(int8_t)(mvs & 255u), dy = (int)(int8_t)((mvs >> 8) & 255u);
+
+    int cstride, pw, ph, rstride, wstride;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, plane, rstride);
+    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
+    const int rw = luma ? g.cw : g.cw >> 1, rh = luma ? g.ch : g.ch >> 1;
+
+    int c[16], p[16];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
+    if (luma) {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                p[4 * y + x] = ref[(size_t)clampi(py + y + dy, 0, rh - 1) * rstride + clampi(px + x + dx, 0, rw - 1)];
+    } else {
+        /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
+        const int xi = dx >> 1, yi = dy >> 1, xf = (dx & 1) * 4, yf = (dy & 1) * 4;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                int xa = clampi(px + x + xi, 0, rw - 1), xb = clampi(px + x + xi + 1, 0, rw - 1);
+                int ya = clampi(py + y + yi, 0, rh - 1), yb = clampi(py + y + yi + 1, 0, rh - 1);
+                int A = ref[(size_t)ya * rstride + xa], Bv = ref[(size_t)ya * rstride + xb];
+                int C = ref[(size_t)yb * rstride + xa], D = ref[(size_t)yb * rstride + xb];
+                p[4 * y + x] = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * Bv + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
+            }
+    }
+    mb_lane_out o;
+    mb_code(lane, false, false, c, p, g, o);
+
+    int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
+    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+    mb_store(l32, valid, o, lv_mb, info, rec, wstride, px, py);
+
+    /* chroma DC records (slots 17, 18) and the empty luma-DC slot 16 */
+    int dc0 = __shfl(o.dclv, base | (l32 & 28) | 0), dc1 = __shfl(o.dclv, base | (l32 & 28) | 1);
+    int dc2 = __shfl(o.dclv, base | (l32 & 28) | 2), dc3 = __shfl(o.dclv, base | (l32 & 28) | 3);
+    if (valid && (l32 == 16 || l32 == 20 || l32 == 24)) {
+        uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : l32 == 20 ? 18 : 16) * 16);
+        uint32_t a = l32 == 24 ? 0u : (((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16));
+        uint32_t b = l32 == 24 ? 0u : (((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16));
+        dst[0] = make_uint4(a, b, 0, 0);
+        dst[1] = make_uint4(0, 0, 0, 0);
+    }
+    /* coded_block_pattern from wave ballots */
+    const unsigned long long bal_nz = __ballot(o.nnz > 0);
+    const unsigned long long bal_dc = __ballot(o.dclv != 0);
+    const uint32_t hnz = (uint32_t)(bal_nz >> base), hdc = (uint32_t)(bal_dc >> base);
+    if (valid && l32 == 0) {
+        int cbpl = 0;
+#pragma unroll
+        for (int qd = 0; qd < 4; qd++)
+            if ((hnz >> (4 * qd)) & 15u) cbpl |= 1 << qd;
+        int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
+        info->cbp = (uint8_t)((cbpc << 4) | cbpl);
+        info->flags = 0;
+    }
+}
+
+/* ================================================================== k_intra
+ * Intra16x16 with DC prediction needs the reconstructed left and top
+ * neighbours, so a slice is a 2-D dependency wavefront.  One block per slice;
+ * wave r owns MB row r of the band and runs one macroblock behind wave r-1.
+ * Only the neighbour *sums* are needed for DC prediction, so waves hand over
+ * five integers per macroblock through a small LDS ring. */
+#define INTRA_MAX_WAVES 16
+
+__global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ int s_bot[INTRA_MAX_WAVES][4][5];
+    const int item = blockIdx.z, s = blockIdx.x, tid = threadIdx.x;
+    const int nw = blockDim.x >> 6;
+    const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31;
+    const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
+    const bool luma = l32 < 16;
+    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
+    const int k = l32 & 3;
+    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
+
+    int cstride, pw, ph, wstride;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
+    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
+
+    for (int cb = r0; cb < r1; cb += nw) {
+        const int nr = min(nw, r1 - cb);
+        const int my = cb + wv;
+        const int steps = g.mbw + nr - 1;
+        int leftY = 0, leftC0 = 0, leftC1 = 0; /* per lane: sums relevant to this lane's plane */
+        for (int step = 0; step < steps; step++) {
+            const int mx = step - wv;
+            if (wv < nr && mx >= 0 && mx < g.mbw) {
+                const int mb = my * g.mbw + mx;
+                const bool aL = mx > 0, aT = my > r0;
+                /* top sums: [0] luma, [1],[2] Cb halves, [3],[4] Cr halves */
+                int t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+                if (aT) {
+                    if (wv > 0) {
+                        const int *sb = s_bot[wv - 1][mx & 3];
+                        t0 = sb[0], t1 = sb[1], t2 = sb[2], t3 = sb[3], t4 = sb[4];
+                    } else {
+                        /* row above belongs to the previous chunk of this slice: re-read its bottom lines */
+                        int ys, us;
+                        const uint8_t *ry = rec_plane(B, g, S.parity, item, 0, ys) + (size_t)(my * 16 - 1) * ys + mx * 16;
+                        const uint8_t *ru = rec_plane(B, g, S.parity, item, 1, us) + (size_t)(my * 8 - 1) * us + mx * 8;
+                        const uint8_t *rv = rec_plane(B, g, S.parity, item, 2, us) + (size_t)(my * 8 - 1) * us + mx * 8;
+                        for (int x = 0; x < 16; x++) t0 += ry[x];
+                        for (int x = 0; x < 4; x++) t1 += ru[x], t2 += ru[4 + x], t3 += rv[x], t4 += rv[4 + x];
+                    }
+                }
+                int pred;
+                if (luma) {
+                    pred = (aL && aT) ? (leftY + t0 + 16) >> 5 : aL ? (leftY + 8) >> 4 : aT ? (t0 + 8) >> 4 : 128;
+                } else {
+                    const int sT = plane == 1 ? ((k & 1) ? t2 : t1) : ((k & 1) ? t4 : t3);
+                    const int sL = (k >> 1) ? leftC1 : leftC0;
+                    bool useT = aT, useL = aL;
+                    if (k == 1 && aT) useL = false;
+                    if (k == 2 && aL) useT = false;
+                    pred = (useT && useL) ? (sT + sL + 4) >> 3 : useT ? (sT + 2) >> 2 : useL ? (sL + 2) >> 2 : 128;
+                }
+                const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
+                int c[16], p[16];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
+                        p[4 * y + x] = pred;
+                    }
+                mb_lane_out o;
+                mb_code(lane, true, true, c, p, g, o);
+
+                int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
+                venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+                const bool st = lane < 32;
+                mb_store(l32, st, o, lv_mb, info, rec, wstride, px, py);
+                /* luma DC record (slot 16, zig-zag order) and chroma DC records */
+                if (st && luma) {
+                    const int rp = blk_y(l32) * 4 + blk_x(l32);
+                    int zi = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (venc_zigzag_ct(i) == rp) zi = i;
+                    lv_mb[16 * 16 + zi] = (int16_t)o.dclv;
+                }
+                int dc0 = __shfl(o.dclv, (l32 & 28) | 0), dc1 = __shfl(o.dclv, (l32 & 28) | 1);
+                int dc2 = __shfl(o.dclv, (l32 & 28) | 2), dc3 = __shfl(o.dclv, (l32 & 28) | 3);
+                if (st && (l32 == 16 || l32 == 20)) {
+                    uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
+                    dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16),
+                                        ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
+                    dst[1] = make_uint4(0, 0, 0, 0);
+                }
+                const uint32_t hnz = (uint32_t)__ballot(o.nnz > 0), hdc = (uint32_t)__ballot(o.dclv != 0);
+                if (lane == 0) {
+                    int cbpl = (hnz & 0xffffu) ? 15 : 0;
+                    int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
+                    info->cbp = (uint8_t)((cbpc << 4) | cbpl);
+                    info->flags = 1;
+                    B.mvsad[(size_t)item * g.nmb + mb] = 0;
+                }
+                /* neighbour sums for the next macroblocks */
+                const int pb = o.rec[12] + o.rec[13] + o.rec[14] + o.rec[15];
+                const int pr = o.rec[3] + o.rec[7] + o.rec[11] + o.rec[15];
+                const int botY = __shfl(pb, 10) + __shfl(pb, 11) + __shfl(pb, 14) + __shfl(pb, 15);
+                const int rightY = __shfl(pr, 5) + __shfl(pr, 7) + __shfl(pr, 13) + __shfl(pr, 15);
+                const int bcb0 = __shfl(pb, 18), bcb1 = __shfl(pb, 19), bcr0 = __shfl(pb, 22), bcr1 = __shfl(pb, 23);
+                const int rcb0 = __shfl(pr, 17), rcb1 = __shfl(pr, 19), rcr0 = __shfl(pr, 21), rcr1 = __shfl(pr, 23);
+                leftY = rightY;
+                leftC0 = plane == 2 ? rcr0 : rcb0;
+                leftC1 = plane == 2 ? rcr1 : rcb1;
+                if (lane == 0) {
+                    int *sb = s_bot[wv][mx & 3];
+                    sb[0] = botY, sb[1] = bcb0, sb[2] = bcb1, sb[3] = bcr0, sb[4] = bcr1;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+/* ================================================================== k_cavlc
+ * Half-wave per macroblock, one lane per syntax element group, in syntax order:
+ *   l32 0 header (slice header for the first MB of a slice, mb_skip_run,
+ *         mb_type, mvd / intra modes, cbp, mb_qp_delta)
+ *       1 Intra16x16 luma DC        2..17 luma blocks 0..15
+ *       18,19 Cb,Cr DC              20..27 Cb,Cr AC blocks
+ * Each lane codes into its own LDS strip; a half-wave prefix sum of the bit
+ * counts gives the concatenation offsets; strips are OR-ed into the
+ * macroblock's bit string in LDS and streamed out to HBM. */
+#define CAVLC_MBS 8
+
+DEVFN void load_levels(const int16_t *src, int c[16]) {
+    const uint4 a = ((const uint4 *)src)[0], b = ((const uint4 *)src)[1];
+    const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c[2 * i] = (int)(int16_t)(wds[i] & 0xffffu);
+        c[2 * i + 1] = (int)(int16_t)(wds[i] >> 16);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_priv[CAVLC_MBS * 32 * VENC_LANE_WORDS];
+    __shared__ uint32_t s_mb[CAVLC_MBS][VENC_MB_WORDS + 2];
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int team = tid >> 5, lane = tid & 63, l32 = lane & 31, base = lane & 32;
+    const int mb_raw = blockIdx.x * CAVLC_MBS + team;
+    const bool valid = mb_raw < g.nmb;
+    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int srow = B.slice_first_row[B.row_slice[my]];
+    const bool aL = mx > 0, aT = my > srow;
+
+    const venc_mbinfo *infos = B.mbinfo + (size_t)item * g.nmb;
+    const venc_mbinfo *info = infos + mb;
+    const int cbp = info->cbp, cbpl = cbp & 15, cbpc = cbp >> 4;
+    const bool i16 = info->flags & 1;
+
+    /* role decode */
+    int slot = 0, first = 0, maxc = 16, nC = 0;
+    bool coded = false;
+    if (l32 == 1) {
+        slot = 16;
+        coded = i16;
+    } else if (l32 >= 2 && l32 < 18) {
+        slot = l32 - 2;
+        if (i16) {
+            first = 1, maxc = 15;
+            coded = cbpl != 0;
+        } else
+            coded = (cbpl >> (slot >> 2)) & 1;
+    } else if (l32 == 18 || l32 == 19) {
+        slot = 17 + (l32 - 18);
+        maxc = 4;
+        nC = -1;
+        coded = cbpc > 0;
+    } else if (l32 >= 20 && l32 < 28) {
+        slot = 19 + (l32 - 20);
+        first = 1, maxc = 15;
+        coded = cbpc == 2;
+    }
+    if (!valid) coded = false;
+    /* nC from neighbouring TotalCoeff (9.2.1) */
+    if (coded && nC == 0) {
+        if (l32 < 18) {
+            const int b = l32 == 1 ? 0 : l32 - 2;
+            const int bx = blk_x(b), by = blk_y(b);
+            int nA = 0, nB = 0;
+            bool avA, avB;
+            if (bx > 0)
+                avA = true, nA = info->nnz[by * 4 + bx - 1];
+            else if ((avA = aL))
+                nA = infos[mb - 1].nnz[by * 4 + 3];
+            if (by > 0)
+                avB = true, nB = info->nnz[(by - 1) * 4 + bx];
+            else if ((avB = aT))
+                nB = infos[mb - g.mbw].nnz[12 + bx];
+            nC = venc_nc(avA, nA, avB, nB);
+        } else {
+            const int kk = (l32 - 20) & 3, nb = 16 + 4 * ((l32 - 20) >> 2);
+            const int bx = kk & 1, by = kk >> 1;
+            int nA = 0, nB = 0;
+            bool avA, avB;
+            if (bx > 0)
+                avA = true, nA = info->nnz[nb + 2 * by];
+            else if ((avA = aL))
+                nA = infos[mb - 1].nnz[nb + 2 * by + 1];
+            if (by > 0)
+                avB = true, nB = info->nnz[nb + bx];
+            else if ((avB = aT))
+                nB = infos[mb - g.mbw].nnz[nb + 2 + bx];
+            nC = venc_nc(avA, nA, avB, nB);
+        }
+    }
+    venc_bitsink bs;
+    venc_bs_init(&bs, s_priv + (team * 32 + l32) * VENC_LANE_WORDS);
+    if (coded) {
+        int c[16];
+        load_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16, c);
+        venc_cavlc_block(&bs, c, first, maxc, nC);
+    }
+    if (l32 == 0 && valid) {
+        if (mx == 0 && my == srow) { /* slice_header(), 7.3.3 */
+            venc_bs_ue(&bs, (uint32_t)mb);
+            venc_bs_ue(&bs, S.is_idr ? 7u : 5u);
+            venc_bs_ue(&bs, 0);
+            venc_bs_put(&bs, (uint32_t)S.frame_num & 15u, 4);
+            if (S.is_idr) {
+                venc_bs_ue(&bs, (uint32_t)S.idr_id[item]);
+                venc_bs_put(&bs, 0, 2); /* no_output_of_prior_pics, long_term_reference */
+            } else {
+                venc_bs_put(&bs, 0, 3); /* override, list modification, adaptive marking */
+            }
+            venc_bs_se(&bs, 0); /* slice_qp_delta */
+            venc_bs_ue(&bs, 1); /* disable_deblocking_filter_idc */
+        }
+        if (i16) {
+            venc_bs_ue(&bs, (uint32_t)(1 + 2 + 4 * cbpc + 12 * (cbpl != 0)));
+            venc_bs_ue(&bs, 0);
+            venc_bs_se(&bs, 0);
+        } else {
+            const uint32_t *mvs = B.mvsad + (size_t)item * g.nmb;
+            const uint32_t me = mvs[mb];
+            const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+            bool aA = aL, aB = aT, aC = aT && (mx + 1 < g.mbw);
+            const bool aD = aT && mx > 0;
+            int ax = 0, ay = 0, bxv = 0, byv = 0, cx = 0, cy = 0;
+            if (aA) {
+                uint32_t m = mvs[mb - 1];
+                ax = (int)(int8_t)(m & 255u), ay = (int)(int8_t)((m >> 8) & 255u);
+            }
+            if (aB) {
+                uint32_t m = mvs[mb - g.mbw];
+                bxv = (int)(int8_t)(m & 255u), byv = (int)(int8_t)((m >> 8) & 255u);
+            }
+            if (aC) {
+                uint32_t m = mvs[mb - g.mbw + 1];
+                cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
+            } else if (aD) {
+                uint32_t m = mvs[mb - g.mbw - 1];
+                aC = true;
+                cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
+            }
+            int pxv, pyv;
+            if (!aB && !aC && aA)
+                pxv = ax, pyv = ay;
+            else if ((int)aA + (int)aB + (int)aC == 1)
+                pxv = aA ? ax : aB ? bxv : cx, pyv = aA ? ay : aB ? byv : cy;
+            else
+                pxv = venc_median3(ax, bxv, cx), pyv = venc_median3(ay, byv, cy);
+            venc_bs_ue(&bs, 0); /* mb_skip_run */
+            venc_bs_ue(&bs, 0); /* mb_type P_L0_16x16 */
+            venc_bs_se(&bs, 4 * (dx - pxv));
+            venc_bs_se(&bs, 4 * (dy - pyv));
+            venc_bs_ue(&bs, venc_cbp_inter_code[cbp]);
+            if (cbp) venc_bs_se(&bs, 0);
+        }
+    }
+    const int nbits = venc_bs_flush(&bs);
+    /* inclusive prefix over the 32 lanes of the team */
+    int incl = nbits;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        int t = __shfl_up(incl, d, 32);
+        if (l32 >= d) incl += t;
+    }
+    int total = __shfl(incl, base | 31);
+    if (total > VENC_MB_WORDS * 32) total = VENC_MB_WORDS * 32; /* cannot happen for QP >= 12; keeps LDS in bounds */
+    const int off = incl - nbits;
+    const int nw = (total + 31) >> 5;
+    for (int j = l32; j < nw + 1; j += 32) s_mb[team][j] = 0;
+    __syncthreads();
+    {
+        const uint32_t *pw = s_priv + (team * 32 + l32) * VENC_LANE_WORDS;
+        const int myw = (nbits + 31) >> 5;
+        for (int j = 0; j < myw; j++) {
+            const int pos = off + 32 * j;
+            if (pos >= VENC_MB_WORDS * 32) break;
+            const uint32_t wd = pw[j];
+            const int shb = pos & 31;
+            atomicOr(&s_mb[team][pos >> 5], wd >> shb);
+            if (shb) atomicOr(&s_mb[team][(pos >> 5) + 1], wd << (32 - shb));
+        }
+    }
+    __syncthreads();
+    if (valid) {
+        uint32_t *dst = B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS;
+        for (int j = l32; j < nw; j += 32) dst[j] = s_mb[team][j];
+        if (l32 == 0) B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)total;
+    }
+}
+
+/* ================================================================== k_scan
+ * One block per item: per-slice exclusive scan of macroblock bit counts and the
+ * slice table (byte offsets inside the frame's output buffer). */
+__global__ __launch_bounds__(1024) void k_scan(venc_geom g, venc_bufs B, venc_step S, venc_slice_out *slice_dev) {
+    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_running;
+    const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
+    uint32_t *offp = B.mboff + (size_t)item * g.nmb;
+    uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
+    venc_slice_out *host_tab = (venc_slice_out *)(slot + sizeof(venc_out_header));
+    uint32_t byte_off = 0;
+    for (int s = 0; s < g.n_slices; s++) {
+        const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
+        if (tid == 0) s_running = 0;
+        __syncthreads();
+        for (int b0 = first; b0 < last; b0 += 1024) {
+            const int i = b0 + tid;
+            const uint32_t v = i < last ? nb[i] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
+                if (lane >= d) incl += t;
+            }
+            if (lane == 63) s_wsum[wv] = incl;
+            __syncthreads();
+            uint32_t wbase = 0, tot = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                uint32_t x = s_wsum[k];
+                if (k < wv) wbase += x;
+                tot += x;
+            }
+            const uint32_t run = s_running;
+            if (i < last) offp[i] = run + wbase + incl - v;
+            __syncthreads();
+            if (tid == 0) s_running = run + tot;
+            __syncthreads();
+        }
+        const uint32_t nbits = s_running;
+        const uint32_t nbytes = (nbits + 1 + 7) >> 3;
+        if (tid == 0) {
+            venc_slice_out so = {byte_off, nbytes, nbits, 0};
+            slice_dev[(size_t)item * g.n_slices + s] = so;
+            host_tab[s] = so;
+        }
+        byte_off += (nbytes + 3u) & ~3u;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        venc_out_header h = {byte_off, (uint32_t)g.n_slices, byte_off > B.out_cap ? 1u : 0u, 0};
+        *(venc_out_header *)slot = h;
+    }
+}
+
+/* ================================================================== k_pack
+ * Owner-gather: output word w of a slice (stream bits [32w, 32w+32)) is built by
+ * the macroblock that contains bit 32w, reading on into the following
+ * macroblocks' bit strings as needed.  No atomics, no pre-zeroed destination;
+ * the destination is the device view of pinned host memory. */
+DEVFN uint32_t fetch_bits(const uint32_t *wds, int pos, int n) { /* 1 <= n <= 32 */
+    const int wi = pos >> 5, shb = pos & 31;
+    const uint64_t two = ((uint64_t)wds[wi] << 32) | (uint64_t)((shb + n > 32) ? wds[wi + 1] : 0u);
+    return (uint32_t)((two >> (64 - shb - n)) & (n == 32 ? 0xffffffffull : ((1ull << n) - 1ull)));
+}
+
+__global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_step S, const venc_slice_out *slice_dev) {
+    const int item = blockIdx.z;
+    const int mb = blockIdx.x * 256 + threadIdx.x;
+    if (mb >= g.nmb) return;
+    const int my = mb / g.mbw;
+    const int s = B.row_slice[my];
+    const venc_slice_out so = slice_dev[(size_t)item * g.n_slices + s];
+    const int last_mb = B.slice_first_row[s + 1] * g.mbw;
+    const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
+    const uint32_t *offp = B.mboff + (size_t)item * g.nmb;
+    const uint32_t *bits = B.mbbits + (size_t)item * g.nmb * VENC_MB_WORDS;
+    uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
+    uint32_t *out = (uint32_t *)(slot + B.out_data_off + so.byte_off);
+
+    const uint32_t T = so.nbits;
+    const uint32_t off = offp[mb], n = nb[mb];
+    uint32_t end = off + n;
+    if (mb == last_mb - 1) end = so.nbytes * 8u; /* owner of the trailing bits */
+    for (uint32_t w = (off + 31u) >> 5; 32u * w < end; w++) {
+        if (so.byte_off + 4u * (w + 1u) > B.out_cap) break;
+        uint32_t pos = 32u * w, val = 0;
+        int got = 0, m = mb;
+        while (got < 32 && m < last_mb) {
+            const uint32_t mo = offp[m], mn = nb[m];
+            const uint32_t local = pos - mo;
+            if (local >= mn) {
+                m++;
+                continue;
+            }
+            uint32_t take = mn - local;
+            if (take > (uint32_t)(32 - got)) take = (uint32_t)(32 - got);
+            const uint32_t v = fetch_bits(bits + (size_t)m * VENC_MB_WORDS, (int)local, (int)take);
+            val = take == 32 ? v : ((val << take) | v);
+            got += (int)take;
+            pos += take;
+            if (local + take == mn) m++;
+        }
+        if (got < 32) {
+            if (pos == T) { /* rbsp_stop_one_bit */
+                val = (val << 1) | 1u;
+                got++;
+            }
+            val = got ? (val << (32 - got)) : 0u;
+        }
+        out[w] = __builtin_bswap32(val);
+    }
+}

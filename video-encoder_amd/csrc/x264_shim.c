@@ -1,0 +1,349 @@
+/*
+ * x264_shim.c -- C99 host side of the drop-in boundary: the subset of the x264
+ * API the reference calls (include/x264.h), implemented on the thin C-ABI of the
+ * HIP engine (include/venc_hip.h).  "Host code stays in C."
+ *
+ * What the reference's caller relies on (all honoured):
+ *  1. all NAL payloads of a frame are one contiguous buffer starting at
+ *     nals[0].p_payload (av_encode.c:802, :810-811, :738);
+ *  2. every NAL starts with a 4-byte length prefix that i_payload includes
+ *     (:722, :727) -- b_annexb = 0 (:392);
+ *  3. SPS bytes 5..7 = profile_idc, constraint flags, level_idc (:692-705);
+ *  4. parameter sets precede slice NALs (:732-746);
+ *  5. i_dts = i_pts, strictly increasing (no B-frames) (:775-776);
+ *  6. b_keyframe set on IDR frames (:783);
+ *  encode may return 0 while the pipeline fills and is drained through
+ *  x264_encoder_delayed_frames (:971-974, :1076-1083).
+ *
+ * Pipeline: frames are queued into an input pool in HBM.  With gop_batch = 1
+ * every call launches one lock-step frame and returns the previous one
+ * (zerolatency: the same one).  With gop_batch = G > 1 the shim waits until G
+ * closed GOPs are queued and advances them together, one kernel sequence per
+ * frame index, so each launch covers G x (macroblocks per frame) work items.
+ */
+#include "../../include/x264.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/venc_hip.h"
+#include "h264_syntax.h"
+
+#define SHIM_MAX_NALS (2 + 256)
+
+typedef struct {
+    int64_t pts;
+    int is_idr;
+    int out_slot;
+    int ticket;
+} shim_frame;
+
+struct x264_t {
+    x264_param_t param;
+    venc_ctx *ctx;
+    int qp, keyint, gop_batch, unit; /* unit = frames per scheduling unit (1 or G*keyint) */
+    int delay;                       /* frames between submission and delivery */
+    int pool;                        /* in/out slots */
+    int64_t n_in, n_out, n_launched;
+    int64_t gop_counter;
+    shim_frame *ring; /* pool entries, indexed by frame number % pool */
+    h264_seq seq;
+    uint8_t *payload;
+    size_t payload_cap;
+    x264_nal_t nals[SHIM_MAX_NALS];
+    int external_input; /* venc_set_input is active (resident mode) */
+};
+
+static const char *const k_presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast",
+                                        "medium",    "slow",      "slower",   "veryslow", "placebo", NULL};
+static const char *const k_tunes[] = {"film", "animation",  "grain",       "stillimage",
+                                      "psnr", "ssim",       "fastdecode",  "zerolatency", NULL};
+static const char *const k_profiles[] = {"baseline", "main", "high", "high10", "high422", "high444", NULL};
+
+static int name_in(const char *s, const char *const *list) {
+    for (; *list; list++)
+        if (!strcmp(s, *list)) return 1;
+    return 0;
+}
+
+int x264_param_default_preset(x264_param_t *param, const char *preset, const char *tune) {
+    if (!param) return -1;
+    memset(param, 0, sizeof(*param));
+    param->i_csp = X264_CSP_I420;
+    param->b_annexb = 1; /* libx264's default; the reference overrides it to 0 (av_encode.c:392) */
+    param->i_fps_num = 25;
+    param->i_fps_den = 1;
+    param->i_keyint_max = 30;
+    param->i_slice_count = 8;
+    param->i_frame_reference = 1;
+    param->rc.i_rc_method = X264_RC_CQP;
+    param->rc.i_qp_constant = 26;
+    param->rc.f_rf_constant = 23.0f;
+    param->hip.i_device = 0;
+    param->hip.i_gop_batch = 1;
+    if (preset) {
+        if (!name_in(preset, k_presets)) return -1;
+        snprintf(param->psz_preset, sizeof(param->psz_preset), "%s", preset);
+    }
+    if (tune) {
+        /* libx264 accepts several tunes separated by , . or space */
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%s", tune);
+        for (char *tok = strtok(buf, ",./-+ "); tok; tok = strtok(NULL, ",./-+ ")) {
+            if (!name_in(tok, k_tunes)) return -1;
+            if (!strcmp(tok, "zerolatency")) param->b_zerolatency = 1;
+        }
+        snprintf(param->psz_tune, sizeof(param->psz_tune), "%.15s", tune);
+    }
+    return 0;
+}
+
+int x264_param_apply_profile(x264_param_t *param, const char *profile) {
+    if (!param) return -1;
+    if (!profile) return 0; /* the reference's default (av_encode.c:105) */
+    if (!name_in(profile, k_profiles)) return -1;
+    snprintf(param->psz_profile, sizeof(param->psz_profile), "%s", profile);
+    return 0; /* the engine always emits Constrained Baseline */
+}
+
+int x264_picture_alloc(x264_picture_t *pic, int i_csp, int i_width, int i_height) {
+    if (!pic || i_csp != X264_CSP_I420 || i_width <= 0 || i_height <= 0 || (i_width & 1) || (i_height & 1)) return -1;
+    memset(pic, 0, sizeof(*pic));
+    const size_t ysz = (size_t)i_width * i_height;
+    uint8_t *buf = (uint8_t *)venc_host_alloc(ysz * 3 / 2);
+    if (!buf) return -1;
+    pic->i_type = X264_TYPE_AUTO;
+    pic->img.i_csp = i_csp;
+    pic->img.i_plane = 3;
+    pic->img.plane[0] = buf;
+    pic->img.plane[1] = buf + ysz;
+    pic->img.plane[2] = buf + ysz + ysz / 4;
+    pic->img.i_stride[0] = i_width;
+    pic->img.i_stride[1] = i_width / 2;
+    pic->img.i_stride[2] = i_width / 2;
+    return 0;
+}
+
+void x264_picture_clean(x264_picture_t *pic) {
+    if (!pic) return;
+    venc_host_free(pic->img.plane[0]);
+    memset(pic, 0, sizeof(*pic));
+}
+
+x264_t *x264_encoder_open(x264_param_t *param) {
+    if (!param || param->i_width <= 0 || param->i_height <= 0) return NULL;
+    x264_t *h = (x264_t *)calloc(1, sizeof(*h));
+    if (!h) return NULL;
+    h->param = *param;
+    int qp = param->rc.i_rc_method == X264_RC_CQP ? param->rc.i_qp_constant : (int)lroundf(param->rc.f_rf_constant);
+    if (qp < 12) qp = 12;
+    if (qp > 51) qp = 51;
+    h->qp = qp;
+    h->keyint = param->i_keyint_max > 0 ? param->i_keyint_max : 30;
+    h->gop_batch = param->hip.i_gop_batch > 1 ? param->hip.i_gop_batch : 1;
+    if (h->gop_batch > VENC_MAX_ITEMS) h->gop_batch = VENC_MAX_ITEMS;
+    if (h->gop_batch > 1) {
+        h->unit = h->gop_batch * h->keyint;
+        h->delay = h->unit;
+        h->pool = 2 * h->unit;
+    } else {
+        h->unit = 1;
+        h->delay = param->b_zerolatency ? 0 : 1;
+        h->pool = 4;
+    }
+    venc_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.width = param->i_width;
+    cfg.height = param->i_height;
+    cfg.qp = qp;
+    cfg.n_slices = param->i_slice_count > 0 ? param->i_slice_count : 1;
+    cfg.max_items = h->gop_batch;
+    cfg.in_slots = h->pool;
+    cfg.out_slots = h->pool;
+    cfg.device = param->hip.i_device;
+    if (venc_open(&cfg, &h->ctx) != 0) {
+        fprintf(stderr, "x264 [venc]: %s\n", venc_last_error());
+        free(h);
+        return NULL;
+    }
+    h->ring = (shim_frame *)calloc((size_t)h->pool, sizeof(shim_frame));
+    h->seq.width = param->i_width;
+    h->seq.height = param->i_height;
+    h->seq.qp = qp;
+    h->seq.fps_num = param->i_fps_num;
+    h->seq.fps_den = param->i_fps_den;
+    h->seq.sar_w = param->vui.i_sar_width;
+    h->seq.sar_h = param->vui.i_sar_height;
+    const int n_slices = venc_n_slices(h->ctx);
+    const size_t coded = (size_t)venc_mb_width(h->ctx) * 16 * venc_mb_height(h->ctx) * 16;
+    h->payload_cap = 512 + (coded + 65536) * 3 / 2 + (size_t)n_slices * 16;
+    h->payload = (uint8_t *)malloc(h->payload_cap);
+    if (!h->ring || !h->payload) {
+        x264_encoder_close(h);
+        return NULL;
+    }
+    return h;
+}
+
+void x264_encoder_close(x264_t *h) {
+    if (!h) return;
+    venc_close(h->ctx);
+    free(h->ring);
+    free(h->payload);
+    free(h);
+}
+
+int x264_encoder_delayed_frames(x264_t *h) { return h ? (int)(h->n_in - h->n_out) : 0; }
+
+/* launch every complete scheduling unit that has not been launched yet;
+ * `flush` also launches a trailing partial unit */
+static int launch_pending(x264_t *h, int flush) {
+    while (h->n_launched < h->n_in) {
+        const int64_t avail = h->n_in - h->n_launched;
+        if (avail < h->unit && !flush) break;
+        const int n = (int)(avail < h->unit ? avail : h->unit);
+        if (h->gop_batch == 1) {
+            const int64_t f = h->n_launched;
+            shim_frame *fr = &h->ring[f % h->pool];
+            int in_slot = h->external_input ? (int)f : (int)(f % h->pool), out_slot = (int)(f % h->pool);
+            int idr_id = (int)(h->gop_counter & 1);
+            if (venc_encode_step(h->ctx, 1, &in_slot, &out_slot, fr->is_idr, (int)(f % h->keyint) & 15, &idr_id) != 0) return -1;
+            if (fr->is_idr) h->gop_counter++;
+            fr->ticket = venc_mark(h->ctx);
+            if (fr->ticket < 0) return -1;
+        } else {
+            const int gops = (n + h->keyint - 1) / h->keyint, rem = n % h->keyint;
+            for (int t = 0; t < h->keyint && t < n; t++) {
+                int in_slots[VENC_MAX_ITEMS], out_slots[VENC_MAX_ITEMS], idr_ids[VENC_MAX_ITEMS];
+                int items = 0;
+                for (int g = 0; g < gops; g++) {
+                    if (g == gops - 1 && rem && t >= rem) break;
+                    const int64_t f = h->n_launched + (int64_t)g * h->keyint + t;
+                    in_slots[items] = h->external_input ? (int)f : (int)(f % h->pool);
+                    out_slots[items] = (int)(f % h->pool);
+                    idr_ids[items] = (int)((h->gop_counter + g) & 1);
+                    items++;
+                }
+                if (!items) break;
+                if (venc_encode_step(h->ctx, items, in_slots, out_slots, t == 0, t & 15, idr_ids) != 0) return -1;
+                const int ticket = venc_mark(h->ctx);
+                if (ticket < 0) return -1;
+                for (int g = 0; g < items; g++) h->ring[(h->n_launched + (int64_t)g * h->keyint + t) % h->pool].ticket = ticket;
+            }
+            h->gop_counter += gops;
+        }
+        h->n_launched += n;
+    }
+    return 0;
+}
+
+/* wait for frame n_out, wrap its slices into NALs, fill the caller's views */
+static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out) {
+    shim_frame *fr = &h->ring[h->n_out % h->pool];
+    if (venc_wait(h->ctx, fr->ticket) != 0) return -1;
+    venc_frame vf;
+    if (venc_get_frame(h->ctx, fr->out_slot, &vf) != 0) return -1;
+    size_t need = 256 + (size_t)vf.n_slices * 16 + (size_t)vf.total_bytes * 3 / 2;
+    if (need > h->payload_cap) {
+        uint8_t *p = (uint8_t *)realloc(h->payload, need);
+        if (!p) return -1;
+        h->payload = p;
+        h->payload_cap = need;
+    }
+    size_t o = 0;
+    int n = 0;
+    const int annexb = h->param.b_annexb;
+    if (fr->is_idr) {
+        uint8_t rbsp[96];
+        size_t k = h264_write_sps(&h->seq, rbsp, sizeof(rbsp));
+        size_t sz = h264_wrap_nal(h->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_SPS, rbsp, k);
+        h->nals[n++] = (x264_nal_t){NAL_PRIORITY_HIGHEST, NAL_SPS, (int)sz, h->payload + o};
+        o += sz;
+        k = h264_write_pps(&h->seq, rbsp, sizeof(rbsp));
+        sz = h264_wrap_nal(h->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_PPS, rbsp, k);
+        h->nals[n++] = (x264_nal_t){NAL_PRIORITY_HIGHEST, NAL_PPS, (int)sz, h->payload + o};
+        o += sz;
+    }
+    const int ref_idc = fr->is_idr ? NAL_PRIORITY_HIGHEST : NAL_PRIORITY_HIGH;
+    const int type = fr->is_idr ? NAL_SLICE_IDR : NAL_SLICE;
+    for (uint32_t s = 0; s < vf.n_slices && n < SHIM_MAX_NALS; s++) {
+        const size_t sz = h264_wrap_nal(h->payload + o, annexb, ref_idc, type, vf.data + vf.slices[s].byte_off, vf.slices[s].nbytes);
+        h->nals[n++] = (x264_nal_t){ref_idc, type, (int)sz, h->payload + o};
+        o += sz;
+    }
+    if (pic_out) {
+        pic_out->i_type = fr->is_idr ? X264_TYPE_IDR : X264_TYPE_P;
+        pic_out->b_keyframe = fr->is_idr;
+        pic_out->i_pts = fr->pts;
+        pic_out->i_dts = fr->pts;
+    }
+    *pp_nal = h->nals;
+    *pi_nal = n;
+    h->n_out++;
+    return (int)o;
+}
+
+int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out) {
+    if (!h || !pp_nal || !pi_nal) return -1;
+    *pp_nal = NULL;
+    *pi_nal = 0;
+    if (pic_in) {
+        if (h->external_input) return -1;
+        if (h->n_in - h->n_out >= h->pool) return -1; /* cannot happen: delay < pool */
+        const int64_t f = h->n_in;
+        shim_frame *fr = &h->ring[f % h->pool];
+        fr->pts = pic_in->i_pts;
+        fr->is_idr = (f % h->keyint) == 0;
+        fr->out_slot = (int)(f % h->pool);
+        fr->ticket = -1;
+        if (venc_upload(h->ctx, (int)(f % h->pool), pic_in->img.plane[0], pic_in->img.i_stride[0], pic_in->img.plane[1],
+                        pic_in->img.i_stride[1], pic_in->img.plane[2], pic_in->img.i_stride[2]) != 0)
+            return -1;
+        /* the caller rewrites pic_in right after this call (av_encode.c:545) */
+        if (venc_upload_sync(h->ctx) != 0) return -1;
+        h->n_in++;
+        if (launch_pending(h, 0) != 0) return -1;
+        if (h->n_in - h->n_out <= h->delay) return 0;
+    } else {
+        if (h->n_in == h->n_out) return 0;
+        if (launch_pending(h, 1) != 0) return -1;
+    }
+    return deliver(h, pp_nal, pi_nal, pic_out);
+}
+
+int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_stride, int n_frames, int64_t first_pts,
+                              x264_venc_sink sink, void *user) {
+    if (!h || !d_frames || n_frames < 1 || h->n_in != h->n_out) return -1;
+    if (venc_set_input(h->ctx, d_frames, (size_t)frame_stride, n_frames) != 0) return -1;
+    h->external_input = 1;
+    /* frame numbering restarts so that resident frame f is input slot f */
+    h->n_in = h->n_out = h->n_launched = 0;
+    int delivered = 0, f = 0;
+    x264_nal_t *nals;
+    int nn;
+    x264_picture_t po;
+    while (f < n_frames || h->n_out < h->n_in) {
+        /* keep the GPU queue full: register frames while output slots are free */
+        while (f < n_frames && h->n_in - h->n_out < h->pool) {
+            shim_frame *fr = &h->ring[h->n_in % h->pool];
+            fr->pts = first_pts + f;
+            fr->is_idr = (f % h->keyint) == 0;
+            fr->out_slot = (int)(h->n_in % h->pool);
+            fr->ticket = -1;
+            h->n_in++;
+            f++;
+            if (launch_pending(h, 0) != 0) return -1;
+        }
+        if (f >= n_frames && launch_pending(h, 1) != 0) return -1;
+        if (h->n_out < h->n_launched) {
+            const int bytes = deliver(h, &nals, &nn, &po);
+            if (bytes < 0) return -1;
+            if (sink && sink(user, nals, nn, bytes, &po) != 0) return -1;
+            delivered++;
+        }
+    }
+    h->external_input = 0;
+    return delivered;
+}
