@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Mpixels/s encoded at fixed QP on synthetic YUV420p.
+
+One "step" = one pass of the hot path over the whole clip of BASELINE.json
+config 2 (1920x1080, 300 frames, IPPP closed GOP 30, QP 26, 8 slices, 16x16
+full search +-16), with the frames already resident in HBM, through the
+reference's own entry points (include/x264.h; the resident-frames extension
+x264_venc_encode_resident drives the same open/encode/flush path as
+av_encode.c:970/:1076-1083 and hands every frame's NAL array to a sink the way
+the reference hands it to its muxer).  Timed region = kernels + write-out of the
+slice RBSPs into pinned host memory + host-side NAL packaging (emulation
+prevention, length prefixes) of every frame.
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank
+encodes its own clip (independent streams / closed GOPs shard with no data-path
+collective -- SURVEY.md section 8e, BASELINE config 4); value = pixels of all
+ranks / max-over-ranks time; scaling = "weak".
+
+Extra objects in the JSON line:
+  roofline      dominant kernel (k_me) against the HBM-read roofline, from HIP
+                events recorded on the engine's stream inside the timed region
+  cpu_baseline  this repo's CPU oracle (kind "port": the reference's own path is
+                un-vendored libx264 and cannot be timed) on a bounded sample
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+WORKLOADS = {
+    # BASELINE.json configs[1] -- the configuration the metric is quoted on
+    "1080p": dict(w=1920, h=1080, frames=300, keyint=30, qp=26, slices=8,
+                  name="1080p30 YUV420p, 300 frames, IPPP closed GOP 30, QP 26, 8 slices, 16x16 full search +-16"),
+    # BASELINE.json configs[2]
+    "2160p": dict(w=3840, h=2160, frames=300, keyint=30, qp=26, slices=8,
+                  name="2160p30 YUV420p, 300 frames, IPPP closed GOP 30, QP 26, 8 slices, 16x16 full search +-16"),
+    "cif": dict(w=352, h=288, frames=300, keyint=30, qp=26, slices=8, name="CIF smoke workload"),
+}
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+ME_ALGO_BYTES_PER_PX = 2.0      # k_me reads cur Y (1.0) + ref Y (1.0) per P-frame pixel
+
+
+def cpu_baseline(wl, frames, threads):
+    """CPU oracle (this repo's C restatement; NOT libx264) on the first `frames` frames of the same clip."""
+    import orc_py
+    venc = importlib.import_module("video-encoder_amd")
+    w, h = wl["w"], wl["h"]
+    clip = [venc.synth_frame(w, h, t) for t in range(frames)]
+    enc = orc_py.Encoder(w, h, qp=wl["qp"], n_slices=wl["slices"], keyint=wl["keyint"], threads=threads)
+    t0 = time.perf_counter()
+    nbytes = 0
+    for y, u, v in clip:
+        nbytes += len(enc.encode(y, u, v).data)
+    dt = time.perf_counter() - t0
+    enc.close()
+    return dict(value=round(frames * w * h / dt / 1e6, 3), unit="Mpixels/s", cores=threads, kind="port",
+                sample="first %d frames (1 I + %d P) of the same %dx%d clip, %d OpenMP threads, %.1f s" % (
+                    frames, frames - 1, w, h, threads, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    venc = importlib.import_module("video-encoder_amd")
+    wl = WORKLOADS[args.workload]
+    w, h, frames, keyint = wl["w"], wl["h"], wl["frames"], wl["keyint"]
+    gop_batch = args.gop_batch or (frames + keyint - 1) // keyint
+    fb = w * h * 3 // 2
+
+    # synthetic clip, generated on the GPU straight into HBM (same bytes as the host generator)
+    clip = torch.empty(frames * fb, dtype=torch.uint8, device="cuda")
+    if venc.hip_lib().venc_synth_device(clip.data_ptr(), fb, w, h, 0, frames, 0x1234ABCD + rank) != 0:
+        raise SystemExit("venc_synth_device failed")
+    torch.cuda.synchronize()
+
+    enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
+                           gop_batch=gop_batch, device=local_rank)
+    if not args.no_profile:
+        enc.profile(True, capacity=8 * frames * max(1, args.steps))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    tally = None
+    for _ in range(args.warmup):
+        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+    if not args.no_profile:
+        enc.profile_read()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
+    barrier()
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        px = world * args.steps * frames * w * h
+        out = {
+            "metric": "Mpixels/s encoded at fixed QP, 1080p & 4K YUV420p; bit-exact vs CPU ref",
+            "value": round(px / dt / 1e6, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "frames_per_step": frames, "gop_batch": gop_batch,
+                       "parallelism": "1 stream per GPU, no collective" if world > 1 else "single GPU",
+                       "bytes_per_step": int(tally.bytes) if tally else None,
+                       "bitstream_fnv1a": "%016x" % tally.fnv1a if tally else None,
+                       "cpu_oracle_note": "bit-exact vs this repo's CPU oracle (tests/); parity with libx264 unpinned"},
+        }
+        if prof:
+            me_ms, me_n = prof.get("k_me", (0.0, 0))
+            total_ms = sum(v[0] for v in prof.values())
+            if me_n:
+                launches_per_step = me_n / args.steps
+                px_per_launch = (frames - (frames + keyint - 1) // keyint) * w * h / launches_per_step
+                algo_bytes = ME_ALGO_BYTES_PER_PX * px_per_launch
+                avg_s = me_ms / me_n * 1e-3
+                achieved = algo_bytes / avg_s / 1e9
+                traffic = None
+                tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(tfile):
+                    try:
+                        traffic = json.load(open(tfile)).get(args.workload, {}).get("k_me_hbm_bytes_per_launch")
+                    except Exception:
+                        traffic = None
+                out["roofline"] = {"bound": "hbm", "kernel": "k_me", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                                   "algorithmic_bytes_per_launch": int(algo_bytes),
+                                   "avg_launch_us": round(avg_s * 1e6, 2), "launches": me_n,
+                                   "absdiff_per_s": round(1089.0 * px_per_launch / avg_s, 1),
+                                   "events_dropped": dropped}
+            out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items()}
+            out["kernel_ms_per_step"]["sum"] = round(total_ms / args.steps, 3)
+        if world == 1 and args.cpu_frames > 0:
+            out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_frames, frames), min(os.cpu_count() or 1, 16))
+        print(json.dumps(out))
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,8 +119,16 @@ int venc_get_frame(venc_ctx *c, int slot, venc_frame *out);
  *   17/18 Cb/Cr DC (4 levels); 19..22 Cb AC; 23..26 Cr AC (levels at 1..15). */
 int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_t dst_bytes);
 
-/* Stand-alone launchers used by micro-benchmarks and tests. */
-int venc_time_kernel(venc_ctx *c, int which, int n_items, int iters, float *ms_per_launch);
+/* Per-kernel timing with HIP events on the engine's own stream (bench.py's
+ * roofline leg).  venc_profile(c, 1, capacity) starts logging one event pair per
+ * kernel launch; venc_profile_read() synchronises, returns per-kernel summed
+ * milliseconds and launch counts (arrays of venc_profile_kernels() entries,
+ * names via venc_profile_name) and clears the log.  Returns 1 if the log
+ * overflowed its capacity. */
+int venc_profile(venc_ctx *c, int enable, int capacity);
+int venc_profile_kernels(void);
+const char *venc_profile_name(int kernel_id);
+int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches);
 
 /* Deterministic synthetic YUV420p source, host side. */
 void venc_synth_frame(int width, int height, int frame_index, uint32_t seed, uint8_t *y, uint8_t *u, uint8_t *v);

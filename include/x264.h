@@ -87,6 +87,7 @@ typedef struct x264_param_t {
     struct {                /* engine extension, not part of libx264 */
         int i_device;       /* HIP device ordinal */
         int i_gop_batch;    /* closed GOPs encoded in lock-step (1 = frame-by-frame streaming) */
+        int i_gop_base;     /* index of this encoder's first GOP in the whole stream (GOP-sharded multi-GPU runs) */
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;
@@ -132,6 +133,14 @@ typedef int (*x264_venc_sink)(void *user, const x264_nal_t *nals, int nal_count,
                               const x264_picture_t *pic_out);
 int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_stride, int n_frames, int64_t first_pts,
                               x264_venc_sink sink, void *user);
+
+/* ready-made sink: frame/byte counters + FNV-1a digest of every payload byte */
+typedef struct {
+    uint64_t frames, bytes, keyframes, fnv1a;
+} x264_venc_tally;
+int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int payload_bytes, const x264_picture_t *pic_out);
+/* the venc_ctx* behind an encoder (for venc_profile / venc_debug_read) */
+void *x264_venc_engine(x264_t *h);
 
 #ifdef __cplusplus
 }

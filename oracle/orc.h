@@ -50,6 +50,8 @@ typedef struct {
     int fps_num, fps_den;
     int sar_w, sar_h;    /* 0 -> no aspect_ratio_info */
     int threads;         /* OpenMP threads (slice / MB-row parallel); <=0 -> 1 */
+    int idr_base;        /* index of the first closed GOP (idr_pic_id = (idr_base + n) & 1): lets a
+                            GOP-sharded run reproduce the single-encoder stream */
 } orc_params;
 
 typedef struct {

@@ -333,6 +333,7 @@ orc_enc *orc_enc_open(const orc_params *p) {
     e->p = *p;
     if (e->p.keyint <= 0) e->p.keyint = 1;
     if (e->p.threads <= 0) e->p.threads = 1;
+    e->idr_count = e->p.idr_base;
     e->mbw = (p->width + 15) / 16;
     e->mbh = (p->height + 15) / 16;
     if (e->p.n_slices < 1) e->p.n_slices = 1;

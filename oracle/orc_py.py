@@ -18,7 +18,7 @@ MAX_NALS = 512
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "keyint", "fps_num", "fps_den",
-                                       "sar_w", "sar_h", "threads")]
+                                       "sar_w", "sar_h", "threads", "idr_base")]
 
 
 class OrcNal(C.Structure):
@@ -87,9 +87,9 @@ class Frame:
 
 
 class Encoder:
-    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1):
+    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0):
         self.L = lib()
-        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads)
+        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base)
         self.h = self.L.orc_enc_open(C.byref(self.params))
         if not self.h:
             raise ValueError("orc_enc_open rejected the parameters")
@@ -138,7 +138,8 @@ class Encoder:
         return np.ctypeslib.as_array(self.L.orc_enc_mb_bits(self.h), (self.nmb,)).copy()
 
     def slice_rows(self):
-        return np.ctypeslib.as_array(self.L.orc_enc_slice_rows(self.h), (self.params.n_slices + 1,)).copy()
+        n = min(max(1, self.params.n_slices), self.mbh)
+        return np.ctypeslib.as_array(self.L.orc_enc_slice_rows(self.h), (n + 1,)).copy()
 
     def recon(self):
         out = []

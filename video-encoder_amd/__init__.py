@@ -73,7 +73,7 @@ class _Rc(C.Structure):
 
 
 class _Hip(C.Structure):
-    _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int)]
+    _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int)]
 
 
 class X264Param(C.Structure):
@@ -98,6 +98,10 @@ X264_CSP_I420 = 1
 X264_TYPE_AUTO = 0
 X264_RC_CQP, X264_RC_CRF = 0, 1
 NAL_SLICE, NAL_SLICE_IDR, NAL_SPS, NAL_PPS, NAL_FILLER = 1, 5, 7, 8, 12
+
+class X264Tally(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("bytes", C.c_uint64), ("keyframes", C.c_uint64), ("fnv1a", C.c_uint64)]
+
 
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(X264Nal), C.c_int, C.c_int, C.POINTER(X264Picture))
 
@@ -138,6 +142,10 @@ def hip_lib():
         L.venc_synth_frame.restype = None
         L.venc_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.venc_synth_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.venc_profile.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.venc_profile_name.restype = C.c_char_p
+        L.venc_profile_name.argtypes = [C.c_int]
+        L.venc_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         _hip = L
     return _hip
 
@@ -159,8 +167,10 @@ def x264_lib():
         L.x264_encoder_delayed_frames.argtypes = [C.c_void_p]
         L.x264_encoder_close.restype = None
         L.x264_encoder_close.argtypes = [C.c_void_p]
-        L.x264_venc_encode_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int64, SINK_FN,
+        L.x264_venc_encode_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_void_p,
                                                 C.c_void_p]
+        L.x264_venc_engine.restype = C.c_void_p
+        L.x264_venc_engine.argtypes = [C.c_void_p]
         _x264 = L
     return _x264
 
@@ -272,7 +282,7 @@ class X264Encoder:
     """Mirror of the reference's x264_context_t usage (av_encode.c:369-444, :543-547, :968-975, :1076-1083)."""
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
-                 tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None):
+                 tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0):
         self.L = x264_lib()
         p = X264Param()
         if self.L.x264_param_default_preset(C.byref(p), preset.encode() if preset else None,
@@ -287,7 +297,7 @@ class X264Encoder:
         else:
             p.rc.i_rc_method, p.rc.i_qp_constant = X264_RC_CQP, qp
         p.i_keyint_max, p.i_slice_count = keyint, slices
-        p.hip.i_device, p.hip.i_gop_batch = device, gop_batch
+        p.hip.i_device, p.hip.i_gop_batch, p.hip.i_gop_base = device, gop_batch, gop_base
         if self.L.x264_param_apply_profile(C.byref(p), profile.encode() if profile else None) != 0:
             raise ValueError("x264: failed to apply profile %s" % profile)
         self.param = p
@@ -357,7 +367,33 @@ class X264Encoder:
                 sink(C.string_at(base, size), lst, pic.contents.i_pts, bool(pic.contents.b_keyframe))
             return 0
         cb = SINK_FN(_cb)
-        r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts, cb, None)
+        r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts,
+                                             C.cast(cb, C.c_void_p), None)
         if r < 0:
             raise VencError("x264_venc_encode_resident failed: %s" % hip_lib().venc_last_error().decode())
         return r
+
+    def encode_resident_tally(self, dev_ptr, frame_stride, n_frames, first_pts=0):
+        """Same, with the C tally sink (no Python in the loop): returns X264Tally."""
+        t = X264Tally()
+        fn = C.cast(self.L.x264_venc_tally_sink, C.c_void_p)
+        r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts, fn,
+                                             C.cast(C.pointer(t), C.c_void_p))
+        if r != n_frames:
+            raise VencError("x264_venc_encode_resident delivered %d of %d frames: %s" % (
+                r, n_frames, hip_lib().venc_last_error().decode()))
+        return t
+
+    # ---- per-kernel HIP-event timing of the engine behind this encoder
+    def profile(self, enable=True, capacity=8192):
+        if hip_lib().venc_profile(self.L.x264_venc_engine(self.h), int(enable), capacity) != 0:
+            raise VencError("venc_profile failed")
+
+    def profile_read(self):
+        H = hip_lib()
+        n = H.venc_profile_kernels()
+        ms, cnt = (C.c_double * n)(), (C.c_int * n)()
+        rc = H.venc_profile_read(self.L.x264_venc_engine(self.h), ms, cnt)
+        if rc < 0:
+            raise VencError("venc_profile_read failed")
+        return {H.venc_profile_name(i).decode(): (ms[i], cnt[i]) for i in range(n)}, bool(rc)

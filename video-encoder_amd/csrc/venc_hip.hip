@@ -50,7 +50,26 @@ struct venc_ctx {
     uint16_t *d_rank, *d_cand;
     int intra_waves;
     int steps_done;
+    /* optional per-kernel HIP-event timing (venc_profile) */
+    int prof_on;
+    hipEvent_t *prof_ev; /* pairs */
+    int *prof_kid;
+    int prof_n, prof_cap;
 };
+
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_COUNT };
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack"};
+
+static void prof_begin(venc_ctx *c, int kid) {
+    if (!c->prof_on || c->prof_n >= c->prof_cap) return;
+    c->prof_kid[c->prof_n] = kid;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream);
+}
+static void prof_end(venc_ctx *c) {
+    if (!c->prof_on || c->prof_n >= c->prof_cap) return;
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream);
+    c->prof_n++;
+}
 
 /* host copies of the small quantiser tables (device copies live in venc_tables.h) */
 static const int h_mf[6][3] = {{13107, 5243, 8066}, {11916, 4660, 7490}, {10082, 4194, 6554},
@@ -97,6 +116,11 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->d_rank);
     (void)hipFree(c->d_cand);
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->prof_ev)
+        for (int i = 0; i < 2 * c->prof_cap; i++)
+            if (c->prof_ev[i]) (void)hipEventDestroy(c->prof_ev[i]);
+    free(c->prof_ev);
+    free(c->prof_kid);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     free(c);
 }
@@ -206,11 +230,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     const size_t G = (size_t)cfg->max_items, nmb = (size_t)g.nmb;
     b.max_items = cfg->max_items;
     b.in_frame_stride = (size_t)g.w * g.h * 3 / 2;
-    if (cfg->in_slots > 0) {
-        OPEN_OK(hipMalloc(&c->d_in, b.in_frame_stride * cfg->in_slots));
-        b.in_base = c->d_in;
-        c->in_frames = cfg->in_slots;
-    }
+    /* the internal input pool is allocated on first use (venc_upload / venc_input_slot_ptr):
+     * resident-input users (venc_set_input) never pay for it */
     b.recon_frame_bytes = (size_t)g.cw * g.ch * 3 / 2;
     OPEN_OK(hipMalloc(&b.recon, 2 * G * b.recon_frame_bytes));
     OPEN_OK(hipMemset(b.recon, 128, 2 * G * b.recon_frame_bytes));
@@ -230,7 +251,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
 
     /* pinned, device-mapped output pool: header | slice table | data */
     b.out_data_off = (uint32_t)((sizeof(venc_out_header) + (size_t)g.n_slices * sizeof(venc_slice_out) + 63) & ~(size_t)63);
-    b.out_cap = (uint32_t)((size_t)g.cw * g.ch + 65536);
+    /* capacity per frame: generous for the QP range; overflow is reported, never silent */
+    b.out_cap = (uint32_t)((size_t)g.cw * g.ch * (cfg->qp < 20 ? 6 : cfg->qp < 30 ? 3 : 2) / 4 + 65536);
     b.out_slot_bytes = ((size_t)b.out_data_off + b.out_cap + 255) & ~(size_t)255;
     OPEN_OK(hipHostMalloc((void **)&c->h_out, b.out_slot_bytes * cfg->out_slots, hipHostMallocMapped));
     memset(c->h_out, 0, b.out_slot_bytes * cfg->out_slots);
@@ -256,8 +278,23 @@ extern "C" void venc_host_free(void *p) {
     if (p) (void)hipHostFree(p);
 }
 
+static int ensure_input_pool(venc_ctx *c) {
+    if (c->d_in) return 0;
+    if (c->cfg.in_slots < 1) {
+        SET_ERR("no internal input pool configured (in_slots = 0)");
+        return -1;
+    }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    const size_t stride = (size_t)c->g.w * c->g.h * 3 / 2;
+    HIP_OK(hipMalloc(&c->d_in, stride * c->cfg.in_slots));
+    c->b.in_base = c->d_in;
+    c->b.in_frame_stride = stride;
+    c->in_frames = c->cfg.in_slots;
+    return 0;
+}
+
 extern "C" void *venc_input_slot_ptr(venc_ctx *c, int slot) {
-    if (!c->d_in || slot < 0 || slot >= c->cfg.in_slots) return NULL;
+    if (slot < 0 || slot >= c->cfg.in_slots || ensure_input_pool(c) != 0) return NULL;
     return c->d_in + (size_t)slot * c->b.in_frame_stride;
 }
 
@@ -274,9 +311,15 @@ extern "C" int venc_set_input(venc_ctx *c, const void *d_frames, size_t frame_st
 
 extern "C" int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int sy, const uint8_t *u, int su, const uint8_t *v,
                            int sv) {
-    if (!c->d_in || c->b.in_base != c->d_in || slot < 0 || slot >= c->cfg.in_slots) {
+    if (slot < 0 || slot >= c->cfg.in_slots) {
         SET_ERR("venc_upload: slot %d not in the internal pool", slot);
         return -1;
+    }
+    if (ensure_input_pool(c) != 0) return -1;
+    if (c->b.in_base != c->d_in) { /* switch back from a borrowed buffer */
+        c->b.in_base = c->d_in;
+        c->b.in_frame_stride = (size_t)c->g.w * c->g.h * 3 / 2;
+        c->in_frames = c->cfg.in_slots;
     }
     HIP_OK(hipSetDevice(c->cfg.device));
     const int w = c->g.w, h = c->g.h;
@@ -322,15 +365,27 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     const venc_geom &g = c->g;
     const venc_bufs &b = c->b;
     if (is_idr) {
+        prof_begin(c, KID_INTRA);
         hipLaunchKernelGGL(k_intra, dim3(g.n_slices, 1, n_items), dim3(64 * c->intra_waves), 0, c->stream, g, b, S);
+        prof_end(c);
     } else {
+        prof_begin(c, KID_ME);
         hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
+        prof_end(c);
+        prof_begin(c, KID_INTER);
         hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, c->stream, g, b, S);
+        prof_end(c);
     }
+    prof_begin(c, KID_CAVLC);
     hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, c->stream, g, b, S);
+    prof_end(c);
+    prof_begin(c, KID_SCAN);
     hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, c->stream, g, b, S, c->d_slice);
+    prof_end(c);
+    prof_begin(c, KID_PACK);
     hipLaunchKernelGGL(k_pack, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, c->stream, g, b, S,
                        (const venc_slice_out *)c->d_slice);
+    prof_end(c);
     HIP_OK(hipGetLastError());
     c->parity ^= 1;
     c->steps_done++;
@@ -407,14 +462,35 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
     return 0;
 }
 
-extern "C" int venc_time_kernel(venc_ctx *c, int which, int n_items, int iters, float *ms_per_launch) {
-    (void)c;
-    (void)which;
-    (void)n_items;
-    (void)iters;
-    (void)ms_per_launch;
-    SET_ERR("venc_time_kernel: not implemented in this build");
-    return -1;
+/* ------------------------------------------------------------------ per-kernel timing */
+extern "C" int venc_profile(venc_ctx *c, int enable, int capacity) {
+    HIP_OK(hipSetDevice(c->cfg.device));
+    if (enable && !c->prof_ev) {
+        c->prof_cap = capacity > 0 ? capacity : 4096;
+        c->prof_ev = (hipEvent_t *)calloc((size_t)2 * c->prof_cap, sizeof(hipEvent_t));
+        c->prof_kid = (int *)calloc((size_t)c->prof_cap, sizeof(int));
+        if (!c->prof_ev || !c->prof_kid) return -1;
+        for (int i = 0; i < 2 * c->prof_cap; i++) HIP_OK(hipEventCreate(&c->prof_ev[i]));
+    }
+    c->prof_on = enable ? 1 : 0;
+    c->prof_n = 0;
+    return 0;
+}
+extern "C" int venc_profile_kernels(void) { return KID_COUNT; }
+extern "C" const char *venc_profile_name(int kid) { return kid >= 0 && kid < KID_COUNT ? k_kernel_names[kid] : ""; }
+/* sums the recorded launches per kernel (after a stream sync) and resets the log */
+extern "C" int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < KID_COUNT; k++) ms_sum[k] = 0.0, launches[k] = 0;
+    for (int i = 0; i < c->prof_n; i++) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, c->prof_ev[2 * i], c->prof_ev[2 * i + 1]));
+        ms_sum[c->prof_kid[i]] += ms;
+        launches[c->prof_kid[i]]++;
+    }
+    const int dropped = c->prof_on && c->prof_n >= c->prof_cap;
+    c->prof_n = 0;
+    return dropped ? 1 : 0;
 }
 
 /* ------------------------------------------------------------------ synthetic source */

@@ -142,6 +142,7 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     if (qp > 51) qp = 51;
     h->qp = qp;
     h->keyint = param->i_keyint_max > 0 ? param->i_keyint_max : 30;
+    h->gop_counter = param->hip.i_gop_base > 0 ? param->hip.i_gop_base : 0;
     h->gop_batch = param->hip.i_gop_batch > 1 ? param->hip.i_gop_batch : 1;
     if (h->gop_batch > VENC_MAX_ITEMS) h->gop_batch = VENC_MAX_ITEMS;
     if (h->gop_batch > 1) {
@@ -347,3 +348,21 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
     h->external_input = 0;
     return delivered;
 }
+
+/* Built-in sink for throughput runs: counts frames and bytes and folds every
+ * payload byte into a 64-bit FNV-1a digest (user points at x264_venc_tally). */
+int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int payload_bytes, const x264_picture_t *pic_out) {
+    x264_venc_tally *t = (x264_venc_tally *)user;
+    (void)pic_out;
+    if (!t || nal_count < 1) return -1;
+    uint64_t hsh = t->fnv1a ? t->fnv1a : 1469598103934665603ull;
+    const uint8_t *p = nals[0].p_payload;
+    for (int i = 0; i < payload_bytes; i++) hsh = (hsh ^ p[i]) * 1099511628211ull;
+    t->fnv1a = hsh;
+    t->frames++;
+    t->bytes += (uint64_t)payload_bytes;
+    t->keyframes += (uint64_t)(pic_out && pic_out->b_keyframe);
+    return 0;
+}
+
+void *x264_venc_engine(x264_t *h) { return h ? h->ctx : NULL; }
