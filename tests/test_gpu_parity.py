@@ -164,3 +164,55 @@ def test_resident_full_size_roundtrip(venc, orc):
         e.close()
         hashes.append(md.hexdigest())
     assert hashes[0] == hashes[1]
+
+
+def _me_run(venc, frames, w, h, dense):
+    import os
+    os.environ["VENC_ME_DENSE"] = "1" if dense else "0"
+    try:
+        eng = venc.Engine(w, h, qp=26, n_slices=4, max_items=1, in_slots=2, out_slots=2)
+    finally:
+        os.environ.pop("VENC_ME_DENSE", None)
+    out = []
+    for t, (y, u, v) in enumerate(frames):
+        eng.upload(t % 2, y, u, v)
+        eng.encode_step([t % 2], [t % 2], t == 0, t & 15, [0])
+        eng.sync()
+        out.append((eng.debug(0).copy(), eng.get_slices(t % 2)))
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("kind", ["synth", "flat", "white_noise", "static_noise", "stripes"])
+def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
+    """The pruned search (k_me) must return the same vectors and SADs as the exhaustive kernel
+    (k_me_dense) and the oracle, including on content where the bound prunes nothing (flat,
+    white noise: dense fallback) and where ties abound (flat, stripes: rank tie-break)."""
+    w, h, n = 352, 288, 4
+    rng = np.random.default_rng(4)
+    if kind == "synth":
+        frames = [venc.synth_frame(w, h, t, 321) for t in range(n)]
+    elif kind == "flat":
+        frames = [(np.full((h, w), 80 + 3 * t, np.uint8), np.full((h // 2, w // 2), 128, np.uint8),
+                   np.full((h // 2, w // 2), 120, np.uint8)) for t in range(n)]
+    elif kind == "white_noise":
+        frames = [tuple(rng.integers(0, 256, s).astype(np.uint8) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2)))
+                  for _ in range(n)]
+    elif kind == "static_noise":
+        base = tuple(rng.integers(0, 256, s).astype(np.uint8) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2)))
+        frames = [base] * n
+    else:
+        yy, xx = np.mgrid[0:h, 0:w]
+        frames = [((((xx + 2 * t) // 4) % 2) * 200 + 20).astype(np.uint8) for t in range(n)]
+        frames = [(f, np.full((h // 2, w // 2), 128, np.uint8), np.full((h // 2, w // 2), 128, np.uint8)) for f in frames]
+    a = _me_run(venc, frames, w, h, dense=False)
+    b = _me_run(venc, frames, w, h, dense=True)
+    enc = orc.Encoder(w, h, qp=26, n_slices=4, keyint=100, threads=8)
+    for t, (y, u, v) in enumerate(frames):
+        enc.encode(y, u, v)
+        assert np.array_equal(a[t][0], b[t][0]), "%s frame %d: pruned != exhaustive" % (kind, t)
+        assert a[t][1] == b[t][1]
+        if t:
+            mv = np.stack([(a[t][0] & 0xff).astype(np.int8), ((a[t][0] >> 8) & 0xff).astype(np.int8)], axis=1)
+            assert np.array_equal(mv, enc.mv()), "%s frame %d: mv != oracle" % (kind, t)
+            assert np.array_equal((a[t][0] >> 16).astype(np.uint16), enc.sad())

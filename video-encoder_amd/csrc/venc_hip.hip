@@ -17,6 +17,7 @@
 
 #include "../../include/venc_hip.h"
 #include "venc_kernels.hip"
+#include "venc_me.hip"
 #include "venc_synth.h"
 
 static thread_local char g_err[512] = "";
@@ -50,6 +51,7 @@ struct venc_ctx {
     uint16_t *d_rank, *d_cand;
     int intra_waves;
     int steps_done;
+    int me_dense; /* VENC_ME_DENSE=1: exhaustive k_me_dense instead of successive elimination */
     /* optional per-kernel HIP-event timing (venc_profile) */
     int prof_on;
     hipEvent_t *prof_ev; /* pairs */
@@ -57,8 +59,8 @@ struct venc_ctx {
     int prof_n, prof_cap;
 };
 
-enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_COUNT };
-static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack"};
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_COUNT };
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum"};
 
 static void prof_begin(venc_ctx *c, int kid) {
     if (!c->prof_on || c->prof_n >= c->prof_cap) return;
@@ -110,6 +112,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.mbbits);
     (void)hipFree(c->b.mbnbits);
     (void)hipFree(c->b.mboff);
+    (void)hipFree(c->b.refsum);
     (void)hipFree(c->d_slice);
     (void)hipFree(c->d_slice_rows);
     (void)hipFree(c->d_row_slice);
@@ -243,6 +246,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.mbbits, G * nmb * VENC_MB_WORDS * 4));
     OPEN_OK(hipMalloc(&b.mbnbits, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
+    b.refsum_stride = (g.cw + 17 + 15) & ~15;
+    b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
+    OPEN_OK(hipMalloc(&b.refsum, G * b.refsum_item * 4));
+    OPEN_OK(hipMemset(b.refsum, 0, G * b.refsum_item * 4));
+    c->me_dense = getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0;
     OPEN_OK(hipMalloc(&c->d_slice, G * g.n_slices * sizeof(venc_slice_out)));
     b.slice_first_row = c->d_slice_rows;
     b.row_slice = c->d_row_slice;
@@ -370,10 +378,19 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         prof_end(c);
     } else {
         prof_begin(c, KID_ME);
-        hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
+        if (c->me_dense)
+            hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
+        else
+            hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
         prof_end(c);
         prof_begin(c, KID_INTER);
         hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, c->stream, g, b, S);
+        prof_end(c);
+    }
+    if (!c->me_dense) { /* block sums of the frame just reconstructed = reference of the next P step */
+        prof_begin(c, KID_REFSUM);
+        hipLaunchKernelGGL(k_refsum, dim3((g.cw + 17 + RS_TW - 1) / RS_TW, (g.ch + 25 + RS_TH - 1) / RS_TH, n_items), dim3(256), 0,
+                           c->stream, g, b, S);
         prof_end(c);
     }
     prof_begin(c, KID_CAVLC);

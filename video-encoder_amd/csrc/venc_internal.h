@@ -10,6 +10,7 @@
  *   mbinfo        [G][nmb] 32 B  = nnz[24] (16 luma raster, 4 Cb, 4 Cr), cbp, flags
  *   mbbits        [G][nmb][VENC_MB_WORDS] u32  MSB-first macroblock bit strings
  *   mbnbits/mboff [G][nmb] u32
+ *   refsum        [G][ch+25][cw+17 (padded)] u32 = S8(x,y) | S8(x+8,y)<<16 of the reference luma
  *   out (pinned host, device-mapped) [out_slots][out_cap] bytes + slice table
  */
 #ifndef VENC_INTERNAL_H
@@ -83,6 +84,9 @@ typedef struct {
     const uint8_t *row_slice;   /* mbh */
     const uint16_t *me_rank;    /* [33*33] candidate (dyi*33+dxi) -> rank */
     const uint16_t *me_cand;    /* [1089] rank -> dyi<<8 | dxi */
+    uint32_t *refsum;           /* [G][p8 rows][refsum_stride] packed 8x8 block sums of the reference (venc_me.hip) */
+    int refsum_stride;          /* dwords per row */
+    size_t refsum_item;         /* dwords per item */
     uint8_t *out_base;          /* device view of the pinned output pool */
     size_t out_slot_bytes;
     uint32_t out_data_off;      /* offset of data[] inside a slot */

@@ -64,56 +64,8 @@ DEVFN int blk_of(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x >> 1) << 
 #define ME_TILE 8
 #define ME_WDW (ME_TILE * 4 + 8) /* window row in dwords: 160 bytes */
 
-__global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ uint32_t s_win[48 * ME_WDW];
-    __shared__ uint32_t s_cur[16 * ME_TILE * 4];
-    __shared__ uint16_t s_rank[VENC_ME_CANDS];
-
-    const int item = blockIdx.z, my = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
-    const int x0 = tx * ME_TILE * 16, y0 = my * 16;
-    int rstride;
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
-    int cstride, pw, ph;
-    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
-
-    for (int i = tid; i < VENC_ME_CANDS; i += 256) s_rank[i] = B.me_rank[i];
-
-    const bool xin = (x0 - 16 >= 0) && (x0 + ME_TILE * 16 + 16 <= g.cw);
-    for (int i = tid; i < 48 * ME_WDW; i += 256) {
-        int r = i / ME_WDW, d = i - r * ME_WDW;
-        int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
-        int xb = x0 - 16 + 4 * d;
-        const uint8_t *row = ref + (size_t)ry * rstride;
-        uint32_t v;
-        if (xin) {
-            v = *(const uint32_t *)(row + xb);
-        } else {
-            v = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
-                ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
-        }
-        s_win[i] = v;
-    }
-    const bool cur_fast = ((g.w & 3) == 0) && (x0 + ME_TILE * 16 <= g.w);
-    for (int i = tid; i < 16 * ME_TILE * 4; i += 256) {
-        int r = i / (ME_TILE * 4), d = i - r * (ME_TILE * 4);
-        int sy = min(y0 + r, g.h - 1);
-        int xb = x0 + 4 * d;
-        const uint8_t *row = cur + (size_t)sy * cstride;
-        uint32_t v;
-        if (cur_fast) {
-            v = *(const uint32_t *)(row + xb);
-        } else {
-            v = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
-                ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
-        }
-        s_cur[i] = v;
-    }
-    __syncthreads();
-
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-    const int mbi = wave * 2 + half;
-    const int mx = tx * ME_TILE + mbi;
-
+/* exhaustive search of one macroblock by one half-wave; returns the minimal key, identical in all 32 lanes */
+DEVFN uint32_t me_dense_half(const uint32_t *s_win, const uint32_t *s_cur, const uint16_t *s_rank, int mbi, int l32) {
     uint32_t c[16][4];
 #pragma unroll
     for (int y = 0; y < 16; y++)
@@ -170,6 +122,60 @@ __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step 
     }
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
+    return best;
+}
+
+__global__ __launch_bounds__(256) void k_me_dense(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_win[48 * ME_WDW];
+    __shared__ uint32_t s_cur[16 * ME_TILE * 4];
+    __shared__ uint16_t s_rank[VENC_ME_CANDS];
+
+    const int item = blockIdx.z, my = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
+    const int x0 = tx * ME_TILE * 16, y0 = my * 16;
+    int rstride;
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    int cstride, pw, ph;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+
+    for (int i = tid; i < VENC_ME_CANDS; i += 256) s_rank[i] = B.me_rank[i];
+
+    const bool xin = (x0 - 16 >= 0) && (x0 + ME_TILE * 16 + 16 <= g.cw);
+    for (int i = tid; i < 48 * ME_WDW; i += 256) {
+        int r = i / ME_WDW, d = i - r * ME_WDW;
+        int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
+        int xb = x0 - 16 + 4 * d;
+        const uint8_t *row = ref + (size_t)ry * rstride;
+        uint32_t v;
+        if (xin) {
+            v = *(const uint32_t *)(row + xb);
+        } else {
+            v = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
+                ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
+        }
+        s_win[i] = v;
+    }
+    const bool cur_fast = ((g.w & 3) == 0) && (x0 + ME_TILE * 16 <= g.w);
+    for (int i = tid; i < 16 * ME_TILE * 4; i += 256) {
+        int r = i / (ME_TILE * 4), d = i - r * (ME_TILE * 4);
+        int sy = min(y0 + r, g.h - 1);
+        int xb = x0 + 4 * d;
+        const uint8_t *row = cur + (size_t)sy * cstride;
+        uint32_t v;
+        if (cur_fast) {
+            v = *(const uint32_t *)(row + xb);
+        } else {
+            v = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
+                ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+        }
+        s_cur[i] = v;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
+    const int mbi = wave * 2 + half;
+    const int mx = tx * ME_TILE + mbi;
+
+    const uint32_t best = me_dense_half(s_win, s_cur, s_rank, mbi, l32);
     if (l32 == 0 && mx < g.mbw) {
         uint32_t cand = B.me_cand[best & 2047u];
         int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
@@ -324,29 +330,74 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
     const int rw = luma ? g.cw : g.cw >> 1, rh = luma ? g.ch : g.ch >> 1;
 
     int c[16], p[16];
+    /* current block: aligned dword rows when the plane geometry allows it, clamped bytes at the display edges */
+    const bool cur_fast = ((g.w & 7) == 0) && (px + 4 <= pw) && (py + 4 <= ph);
+    if (cur_fast) {
 #pragma unroll
-    for (int y = 0; y < 4; y++)
+        for (int y = 0; y < 4; y++) {
+            const uint32_t v = *(const uint32_t *)(cur + (size_t)(py + y) * cstride + px);
+            c[4 * y] = (int)(v & 255u), c[4 * y + 1] = (int)((v >> 8) & 255u);
+            c[4 * y + 2] = (int)((v >> 16) & 255u), c[4 * y + 3] = (int)(v >> 24);
+        }
+    } else {
 #pragma unroll
-        for (int x = 0; x < 4; x++) c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
+    }
+    /* prediction: the reference block sits at an arbitrary byte offset; interior blocks fetch two
+     * aligned dwords per row and realign with v_alignbyte, blocks touching the frame edge clamp per sample */
+    const int xi = luma ? dx : dx >> 1, yi = luma ? dy : dy >> 1;
+    const int x0 = px + xi, y0 = py + yi;
+    const bool ref_fast = x0 >= 0 && x0 + 8 <= rw && y0 >= 0 && y0 + 5 <= rh;
     if (luma) {
+        if (ref_fast) {
+            const uint32_t sh = (uint32_t)(x0 & 3);
+            const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                const uint32_t *rw32 = (const uint32_t *)(rp + (size_t)y * rstride);
+                const uint32_t v = __builtin_amdgcn_alignbyte(rw32[1], rw32[0], sh);
+                p[4 * y] = (int)(v & 255u), p[4 * y + 1] = (int)((v >> 8) & 255u);
+                p[4 * y + 2] = (int)((v >> 16) & 255u), p[4 * y + 3] = (int)(v >> 24);
+            }
+        } else {
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+                    p[4 * y + x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
+        }
+    } else {
+        /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
+        const int xf = (dx & 1) * 4, yf = (dy & 1) * 4;
+        int smp[5][5];
+        if (ref_fast) {
+            const uint32_t sh = (uint32_t)(x0 & 3);
+            const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
+#pragma unroll
+            for (int y = 0; y < 5; y++) {
+                const uint32_t *rw32 = (const uint32_t *)(rp + (size_t)y * rstride);
+                const uint32_t d0 = rw32[0], d1 = rw32[1];
+                const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                const uint32_t e = __builtin_amdgcn_alignbyte(0u, d1, sh); /* byte x0+4 in its low byte */
+                smp[y][0] = (int)(v & 255u), smp[y][1] = (int)((v >> 8) & 255u);
+                smp[y][2] = (int)((v >> 16) & 255u), smp[y][3] = (int)(v >> 24);
+                smp[y][4] = (int)(e & 255u);
+            }
+        } else {
+#pragma unroll
+            for (int y = 0; y < 5; y++)
+#pragma unroll
+                for (int x = 0; x < 5; x++)
+                    smp[y][x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
+        }
 #pragma unroll
         for (int y = 0; y < 4; y++)
 #pragma unroll
             for (int x = 0; x < 4; x++)
-                p[4 * y + x] = ref[(size_t)clampi(py + y + dy, 0, rh - 1) * rstride + clampi(px + x + dx, 0, rw - 1)];
-    } else {
-        /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
-        const int xi = dx >> 1, yi = dy >> 1, xf = (dx & 1) * 4, yf = (dy & 1) * 4;
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                int xa = clampi(px + x + xi, 0, rw - 1), xb = clampi(px + x + xi + 1, 0, rw - 1);
-                int ya = clampi(py + y + yi, 0, rh - 1), yb = clampi(py + y + yi + 1, 0, rh - 1);
-                int A = ref[(size_t)ya * rstride + xa], Bv = ref[(size_t)ya * rstride + xb];
-                int C = ref[(size_t)yb * rstride + xa], D = ref[(size_t)yb * rstride + xb];
-                p[4 * y + x] = ((8 - xf) * (8 - yf) * A + xf * (8 - yf) * Bv + (8 - xf) * yf * C + xf * yf * D + 32) >> 6;
-            }
+                p[4 * y + x] = ((8 - xf) * (8 - yf) * smp[y][x] + xf * (8 - yf) * smp[y][x + 1] + (8 - xf) * yf * smp[y + 1][x] +
+                                xf * yf * smp[y + 1][x + 1] + 32) >> 6;
     }
     mb_lane_out o;
     mb_code(lane, false, false, c, p, g, o);

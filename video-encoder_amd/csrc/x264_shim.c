@@ -38,6 +38,12 @@ typedef struct {
     int is_idr;
     int out_slot;
     int ticket;
+    int assembled;      /* NALs of this frame are packaged in payload[] */
+    uint8_t *payload;   /* grown on demand, reused by the next frame that maps to this ring entry */
+    size_t payload_cap;
+    int payload_size;
+    int n_nals;
+    x264_nal_t *nals;   /* nal_cap entries */
 } shim_frame;
 
 struct x264_t {
@@ -47,12 +53,11 @@ struct x264_t {
     int delay;                       /* frames between submission and delivery */
     int pool;                        /* in/out slots */
     int64_t n_in, n_out, n_launched;
+    int64_t n_asm; /* frames [0, n_asm) were packaged unit by unit, in completion order */
     int64_t gop_counter;
     shim_frame *ring; /* pool entries, indexed by frame number % pool */
     h264_seq seq;
-    uint8_t *payload;
-    size_t payload_cap;
-    x264_nal_t nals[SHIM_MAX_NALS];
+    int nal_cap;
     int external_input; /* venc_set_input is active (resident mode) */
 };
 
@@ -177,13 +182,17 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     h->seq.fps_den = param->i_fps_den;
     h->seq.sar_w = param->vui.i_sar_width;
     h->seq.sar_h = param->vui.i_sar_height;
-    const int n_slices = venc_n_slices(h->ctx);
-    const size_t coded = (size_t)venc_mb_width(h->ctx) * 16 * venc_mb_height(h->ctx) * 16;
-    h->payload_cap = 512 + (coded + 65536) * 3 / 2 + (size_t)n_slices * 16;
-    h->payload = (uint8_t *)malloc(h->payload_cap);
-    if (!h->ring || !h->payload) {
+    h->nal_cap = 2 + venc_n_slices(h->ctx);
+    if (!h->ring) {
         x264_encoder_close(h);
         return NULL;
+    }
+    for (int i = 0; i < h->pool; i++) {
+        h->ring[i].nals = (x264_nal_t *)calloc((size_t)h->nal_cap, sizeof(x264_nal_t));
+        if (!h->ring[i].nals) {
+            x264_encoder_close(h);
+            return NULL;
+        }
     }
     return h;
 }
@@ -191,8 +200,12 @@ x264_t *x264_encoder_open(x264_param_t *param) {
 void x264_encoder_close(x264_t *h) {
     if (!h) return;
     venc_close(h->ctx);
+    if (h->ring)
+        for (int i = 0; i < h->pool; i++) {
+            free(h->ring[i].payload);
+            free(h->ring[i].nals);
+        }
     free(h->ring);
-    free(h->payload);
     free(h);
 }
 
@@ -240,18 +253,22 @@ static int launch_pending(x264_t *h, int flush) {
     return 0;
 }
 
-/* wait for frame n_out, wrap its slices into NALs, fill the caller's views */
-static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out) {
-    shim_frame *fr = &h->ring[h->n_out % h->pool];
+/* wait for frame f on the GPU and package its slice RBSPs into NALs (host C, a4.6) */
+static int assemble_frame(x264_t *h, int64_t f) {
+    shim_frame *fr = &h->ring[f % h->pool];
+    if (fr->assembled) return 0;
     if (venc_wait(h->ctx, fr->ticket) != 0) return -1;
     venc_frame vf;
     if (venc_get_frame(h->ctx, fr->out_slot, &vf) != 0) return -1;
-    size_t need = 256 + (size_t)vf.n_slices * 16 + (size_t)vf.total_bytes * 3 / 2;
-    if (need > h->payload_cap) {
-        uint8_t *p = (uint8_t *)realloc(h->payload, need);
-        if (!p) return -1;
-        h->payload = p;
-        h->payload_cap = need;
+    const size_t need = 256 + (size_t)vf.n_slices * 16 + (size_t)vf.total_bytes * 3 / 2;
+    if (need > fr->payload_cap) {
+        free(fr->payload);
+        fr->payload_cap = need + need / 4;
+        fr->payload = (uint8_t *)malloc(fr->payload_cap);
+        if (!fr->payload) {
+            fr->payload_cap = 0;
+            return -1;
+        }
     }
     size_t o = 0;
     int n = 0;
@@ -259,31 +276,63 @@ static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *
     if (fr->is_idr) {
         uint8_t rbsp[96];
         size_t k = h264_write_sps(&h->seq, rbsp, sizeof(rbsp));
-        size_t sz = h264_wrap_nal(h->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_SPS, rbsp, k);
-        h->nals[n++] = (x264_nal_t){NAL_PRIORITY_HIGHEST, NAL_SPS, (int)sz, h->payload + o};
+        size_t sz = h264_wrap_nal(fr->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_SPS, rbsp, k);
+        fr->nals[n++] = (x264_nal_t){NAL_PRIORITY_HIGHEST, NAL_SPS, (int)sz, fr->payload + o};
         o += sz;
         k = h264_write_pps(&h->seq, rbsp, sizeof(rbsp));
-        sz = h264_wrap_nal(h->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_PPS, rbsp, k);
-        h->nals[n++] = (x264_nal_t){NAL_PRIORITY_HIGHEST, NAL_PPS, (int)sz, h->payload + o};
+        sz = h264_wrap_nal(fr->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_PPS, rbsp, k);
+        fr->nals[n++] = (x264_nal_t){NAL_PRIORITY_HIGHEST, NAL_PPS, (int)sz, fr->payload + o};
         o += sz;
     }
     const int ref_idc = fr->is_idr ? NAL_PRIORITY_HIGHEST : NAL_PRIORITY_HIGH;
     const int type = fr->is_idr ? NAL_SLICE_IDR : NAL_SLICE;
-    for (uint32_t s = 0; s < vf.n_slices && n < SHIM_MAX_NALS; s++) {
-        const size_t sz = h264_wrap_nal(h->payload + o, annexb, ref_idc, type, vf.data + vf.slices[s].byte_off, vf.slices[s].nbytes);
-        h->nals[n++] = (x264_nal_t){ref_idc, type, (int)sz, h->payload + o};
+    for (uint32_t s = 0; s < vf.n_slices && n < h->nal_cap; s++) {
+        const size_t sz = h264_wrap_nal(fr->payload + o, annexb, ref_idc, type, vf.data + vf.slices[s].byte_off, vf.slices[s].nbytes);
+        fr->nals[n++] = (x264_nal_t){ref_idc, type, (int)sz, fr->payload + o};
         o += sz;
     }
+    fr->n_nals = n;
+    fr->payload_size = (int)o;
+    fr->assembled = 1;
+    return 0;
+}
+
+/* package the oldest launched unit in the order its frames complete on the GPU
+ * (frame index t of every GOP after step t), so the host works while later steps run */
+static int assemble_next_unit(x264_t *h) {
+    if (h->n_asm >= h->n_launched) return 0;
+    const int64_t base = h->n_asm;
+    const int64_t left = h->n_launched - base;
+    const int n = (int)(left < h->unit ? left : h->unit);
+    if (h->gop_batch == 1) {
+        if (assemble_frame(h, base) != 0) return -1;
+    } else {
+        const int gops = (n + h->keyint - 1) / h->keyint;
+        for (int t = 0; t < h->keyint; t++)
+            for (int g = 0; g < gops; g++) {
+                const int64_t k = (int64_t)g * h->keyint + t;
+                if (k < n && assemble_frame(h, base + k) != 0) return -1;
+            }
+    }
+    h->n_asm += n;
+    return 0;
+}
+
+/* hand frame n_out to the caller */
+static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out) {
+    shim_frame *fr = &h->ring[h->n_out % h->pool];
+    if (assemble_frame(h, h->n_out) != 0) return -1;
     if (pic_out) {
         pic_out->i_type = fr->is_idr ? X264_TYPE_IDR : X264_TYPE_P;
         pic_out->b_keyframe = fr->is_idr;
         pic_out->i_pts = fr->pts;
         pic_out->i_dts = fr->pts;
     }
-    *pp_nal = h->nals;
-    *pi_nal = n;
+    *pp_nal = fr->nals;
+    *pi_nal = fr->n_nals;
     h->n_out++;
-    return (int)o;
+    if (h->n_asm < h->n_out) h->n_asm = h->n_out;
+    return fr->payload_size;
 }
 
 int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out) {
@@ -299,6 +348,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         fr->is_idr = (f % h->keyint) == 0;
         fr->out_slot = (int)(f % h->pool);
         fr->ticket = -1;
+        fr->assembled = 0;
         if (venc_upload(h->ctx, (int)(f % h->pool), pic_in->img.plane[0], pic_in->img.i_stride[0], pic_in->img.plane[1],
                         pic_in->img.i_stride[1], pic_in->img.plane[2], pic_in->img.i_stride[2]) != 0)
             return -1;
@@ -320,7 +370,7 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
     if (venc_set_input(h->ctx, d_frames, (size_t)frame_stride, n_frames) != 0) return -1;
     h->external_input = 1;
     /* frame numbering restarts so that resident frame f is input slot f */
-    h->n_in = h->n_out = h->n_launched = 0;
+    h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
     int delivered = 0, f = 0;
     x264_nal_t *nals;
     int nn;
@@ -333,12 +383,15 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
             fr->is_idr = (f % h->keyint) == 0;
             fr->out_slot = (int)(h->n_in % h->pool);
             fr->ticket = -1;
+            fr->assembled = 0;
             h->n_in++;
             f++;
             if (launch_pending(h, 0) != 0) return -1;
         }
         if (f >= n_frames && launch_pending(h, 1) != 0) return -1;
-        if (h->n_out < h->n_launched) {
+        /* package the oldest unit while the GPU works on the next one, then hand it over in display order */
+        if (assemble_next_unit(h) != 0) return -1;
+        while (h->n_out < h->n_asm) {
             const int bytes = deliver(h, &nals, &nn, &po);
             if (bytes < 0) return -1;
             if (sink && sink(user, nals, nn, bytes, &po) != 0) return -1;
@@ -355,9 +408,17 @@ int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int 
     x264_venc_tally *t = (x264_venc_tally *)user;
     (void)pic_out;
     if (!t || nal_count < 1) return -1;
+    /* FNV-1a folded over 8-byte words (tail bytes one by one): a digest that costs about a memcpy,
+     * like the payload copy the reference's muxer makes (av_encode.c:802) */
     uint64_t hsh = t->fnv1a ? t->fnv1a : 1469598103934665603ull;
     const uint8_t *p = nals[0].p_payload;
-    for (int i = 0; i < payload_bytes; i++) hsh = (hsh ^ p[i]) * 1099511628211ull;
+    int i = 0;
+    for (; i + 8 <= payload_bytes; i += 8) {
+        uint64_t wd;
+        memcpy(&wd, p + i, 8);
+        hsh = (hsh ^ wd) * 1099511628211ull;
+    }
+    for (; i < payload_bytes; i++) hsh = (hsh ^ p[i]) * 1099511628211ull;
     t->fnv1a = hsh;
     t->frames++;
     t->bytes += (uint64_t)payload_bytes;
