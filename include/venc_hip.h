@@ -80,7 +80,8 @@ size_t venc_frame_bytes(const venc_ctx *c); /* w*h*3/2: size of one input slot *
 /* Input.  venc_upload copies host planes into pool slot `slot` (async on the
  * copy stream); the source may be reused once venc_upload_sync() returns.
  * venc_set_input borrows caller-owned device memory laid out as consecutive
- * I420 frames (frame_stride bytes apart) instead of the internal pool. */
+ * I420 frames (frame_stride bytes apart, pointer and stride multiples of 16)
+ * instead of the internal pool. */
 int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int stride_y, const uint8_t *u, int stride_u,
                 const uint8_t *v, int stride_v);
 int venc_upload_sync(venc_ctx *c);
@@ -114,6 +115,8 @@ int venc_get_frame(venc_ctx *c, int slot, venc_frame *out);
  *        3: mbnbits u32[nmb]
  *        4/5/6: reconstructed Y/U/V plane (coded size) of the last step
  *        7: mboff   u32[nmb]
+ *        8: packed 8x8 block sums of the last reconstruction, u32[ch+25][(cw+32) & ~15]
+ *           = S8(x-16,y-16) | S8(x-8,y-16) << 16 (motion-search lower bounds)
  * Level record per macroblock (27 blocks x 16 levels, scan order):
  *   0..15 luma 4x4 blocks in luma4x4BlkIdx order; 16 Intra16x16 luma DC;
  *   17/18 Cb/Cr DC (4 levels); 19..22 Cb AC; 23..26 Cr AC (levels at 1..15). */

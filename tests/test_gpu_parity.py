@@ -216,3 +216,22 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
             mv = np.stack([(a[t][0] & 0xff).astype(np.int8), ((a[t][0] >> 8) & 0xff).astype(np.int8)], axis=1)
             assert np.array_equal(mv, enc.mv()), "%s frame %d: mv != oracle" % (kind, t)
             assert np.array_equal((a[t][0] >> 16).astype(np.uint16), enc.sad())
+
+
+def test_reference_block_sums_plane(venc):
+    """k_refsum: P8(x,y) = S8(x,y) | S8(x+8,y) << 16 over the edge-replicated reconstruction."""
+    w, h = 352, 288
+    eng = venc.Engine(w, h, qp=30, n_slices=2, max_items=1, in_slots=1, out_slots=1)
+    eng.upload(0, *venc.synth_frame(w, h, 0, 9))
+    eng.encode_step([0], [0], True, 0, [0])
+    eng.sync()
+    rec = eng.debug(4).astype(np.int64)
+    p8 = eng.debug(8)
+    ch, cw = rec.shape
+    pad = np.pad(rec, ((16, 32), (16, 32)), mode="edge")
+    c = np.cumsum(np.cumsum(np.pad(pad, ((1, 0), (1, 0))), 0), 1)
+    s8 = c[8:, 8:] - c[:-8, 8:] - c[8:, :-8] + c[:-8, :-8]          # s8[Y][X] = block sum at picture (X-16, Y-16)
+    H, W = ch + 25, cw + 17
+    want = (s8[:H, :W] | (s8[:H, 8:W + 8] << 16)).astype(np.uint32)
+    assert np.array_equal(p8[:H, :W], want)
+    eng.close()

@@ -257,7 +257,8 @@ class Engine:
         cw, ch = self.mbw * 16, self.mbh * 16
         shapes = {0: ((self.nmb,), np.uint32), 1: ((self.nmb, 27, 16), np.int16), 2: ((self.nmb, 32), np.uint8),
                   3: ((self.nmb,), np.uint32), 4: ((ch, cw), np.uint8), 5: ((ch // 2, cw // 2), np.uint8),
-                  6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32)}
+                  6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32),
+                  8: ((ch + 25, (cw + 32) & ~15), np.uint32)}
         shape, dt = shapes[what]
         a = np.empty(shape, dt)
         self._ok(self.L.venc_debug_read(self.h, what, item, a.ctypes.data, a.nbytes), "venc_debug_read")

@@ -311,6 +311,10 @@ extern "C" int venc_set_input(venc_ctx *c, const void *d_frames, size_t frame_st
         SET_ERR("venc_set_input: bad arguments");
         return -1;
     }
+    if ((((uintptr_t)d_frames) | frame_stride) & 15) {
+        SET_ERR("venc_set_input: d_frames and frame_stride must be multiples of 16 bytes");
+        return -1;
+    }
     c->b.in_base = (const uint8_t *)d_frames;
     c->b.in_frame_stride = frame_stride;
     c->in_frames = n_frames;
@@ -469,6 +473,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         case 5: src = rec + (size_t)g.cw * g.ch, n = (size_t)g.cw * g.ch / 4; break;
         case 6: src = rec + (size_t)g.cw * g.ch * 5 / 4, n = (size_t)g.cw * g.ch / 4; break;
         case 7: src = c->b.mboff + item * nmb, n = nmb * 4; break;
+        case 8: src = c->b.refsum + item * c->b.refsum_item, n = c->b.refsum_item * 4; break;
         default: SET_ERR("venc_debug_read: unknown selector %d", what); return -1;
     }
     if (dst_bytes < n) {

@@ -21,52 +21,95 @@
  * macroblock instead of 1089.
  */
 
-#define RS_TW 64 /* k_refsum tile: outputs per block, x */
-#define RS_TH 32
+#define RS_TW 128 /* k_refsum tile: output columns per block */
+#define RS_TH 32  /* output rows per block */
+#define RS_PD 37  /* pixel row stride in dwords (36 used) */
+#define RS_HG 34  /* groups of 4 columns carrying horizontal 8-sums: columns [0, 136) */
 
 /* P8 plane geometry: positions x in [-16, cw], y in [-16, ch + 8] */
 DEVFN int p8_width(const venc_geom &g) { return g.cw + 17; }
 DEVFN int p8_height(const venc_geom &g) { return g.ch + 25; }
 
+DEVFN uint2 pk_add_u16x4(uint2 a, uint2 b) { /* four independent u16 lanes, no carries across (sums < 2^16) */
+    return make_uint2(a.x + b.x, a.y + b.y);
+}
+DEVFN uint2 pk_sub_u16x4(uint2 a, uint2 b) { /* every lane of a >= the same lane of b */
+    return make_uint2(a.x - b.x, a.y - b.y);
+}
+
+/* Block sums of the frame just reconstructed.  Tile = 128 x 32 plane positions.
+ *   A  pixels (edge-clamped) -> LDS as dwords
+ *   B  horizontal 8-sums with v_qsad_pk_u16_u8 against zero: one instruction yields the four
+ *      sliding 4-byte sums of a dword pair; two of them added give four 8-sums (packed u16x4)
+ *   C  vertical 8-sums by a sliding window down 4-row segments (packed u16x4 adds)
+ *   D  pair S8(x) with S8(x+8) and store 16 bytes per lane */
 __global__ __launch_bounds__(256) void k_refsum(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ uint8_t s_px[RS_TH + 7][RS_TW + 8 + 7 + 1]; /* 39 x 80 */
-    __shared__ uint16_t s_h8[RS_TH + 7][RS_TW + 8];        /* horizontal 8-sums, 72 per row */
+    __shared__ uint32_t s_px[(RS_TH + 7) * RS_PD];
+    __shared__ uint2 s_h8[(RS_TH + 7) * RS_HG];
+    __shared__ uint2 s_s8[RS_TH * RS_HG];
     const int item = blockIdx.z, tid = threadIdx.x;
-    const int ox = blockIdx.x * RS_TW - 16, oy = blockIdx.y * RS_TH - 16; /* picture coords of output (0,0) */
+    const int ox = blockIdx.x * RS_TW - 16, oy = blockIdx.y * RS_TH - 16; /* picture coords of plane position (0,0) of the tile */
     int rstride;
-    const uint8_t *ref = rec_plane(B, g, S.parity, item, 0, rstride); /* the frame just reconstructed */
-    /* pixels needed: x in [ox, ox + 64 + 8 + 7), y in [oy, oy + 32 + 7) */
-    for (int i = tid; i < (RS_TH + 7) * (RS_TW + 15); i += 256) {
-        const int r = i / (RS_TW + 15), c = i - r * (RS_TW + 15);
-        s_px[r][c] = ref[(size_t)clampi(oy + r, 0, g.ch - 1) * rstride + clampi(ox + c, 0, g.cw - 1)];
+    const uint8_t *ref = rec_plane(B, g, S.parity, item, 0, rstride);
+    /* A: pixels x in [ox, ox + 144), y in [oy, oy + 39) */
+    const bool xin = ox >= 0 && ox + 144 <= g.cw;
+    for (int i = tid; i < (RS_TH + 7) * 36; i += 256) {
+        const int r = i / 36, d = i - r * 36;
+        const uint8_t *row = ref + (size_t)clampi(oy + r, 0, g.ch - 1) * rstride;
+        const int xb = ox + 4 * d;
+        uint32_t v;
+        if (xin)
+            v = *(const uint32_t *)(row + xb);
+        else
+            v = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
+                ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
+        s_px[r * RS_PD + d] = v;
     }
     __syncthreads();
-    for (int i = tid; i < (RS_TH + 7) * (RS_TW + 8); i += 256) {
-        const int r = i / (RS_TW + 8), c = i - r * (RS_TW + 8);
-        int s = 0;
+    /* B: H8 for 34 groups x 39 rows */
+    for (int i = tid; i < (RS_TH + 7) * RS_HG; i += 256) {
+        const int r = i / RS_HG, gq = i - r * RS_HG;
+        const uint32_t *p = s_px + r * RS_PD + gq;
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        const unsigned long long h4a = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d1 << 32) | d0, 0u, 0ull);
+        const unsigned long long h4b = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d2 << 32) | d1, 0u, 0ull);
+        s_h8[i] = pk_add_u16x4(make_uint2((uint32_t)h4a, (uint32_t)(h4a >> 32)), make_uint2((uint32_t)h4b, (uint32_t)(h4b >> 32)));
+    }
+    __syncthreads();
+    /* C: S8 for 32 rows: 8 segments of 4 rows x 34 groups */
+    for (int i = tid; i < 8 * RS_HG; i += 256) {
+        const int seg = i / RS_HG, gq = i - seg * RS_HG;
+        const uint2 *col = s_h8 + (seg * 4) * RS_HG + gq;
+        uint2 acc = col[0];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s += s_px[r][c + k];
-        s_h8[r][c] = (uint16_t)s;
+        for (int k = 1; k < 8; k++) acc = pk_add_u16x4(acc, col[k * RS_HG]);
+        s_s8[(seg * 4) * RS_HG + gq] = acc;
+#pragma unroll
+        for (int k = 1; k < 4; k++) {
+            acc = pk_sub_u16x4(pk_add_u16x4(acc, col[(k + 7) * RS_HG]), col[(k - 1) * RS_HG]);
+            s_s8[(seg * 4 + k) * RS_HG + gq] = acc;
+        }
     }
     __syncthreads();
-    const int pw = B.refsum_stride, W = p8_width(g), H = p8_height(g);
+    /* D: P8(x) = S8(x) | S8(x+8) << 16, four positions (one group) per lane */
+    const int W = p8_width(g), H = p8_height(g);
     uint32_t *dst = B.refsum + (size_t)item * B.refsum_item;
-    for (int i = tid; i < RS_TH * RS_TW; i += 256) {
-        const int r = i / RS_TW, c = i - r * RS_TW;
-        const int X = blockIdx.x * RS_TW + c, Y = blockIdx.y * RS_TH + r; /* plane coords */
-        if (X < W && Y < H) {
-            uint32_t a = 0, b = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                a += s_h8[r + k][c];
-                b += s_h8[r + k][c + 8];
-            }
-            dst[(size_t)Y * pw + X] = a | (b << 16);
+    for (int i = tid; i < RS_TH * 32; i += 256) {
+        const int r = i >> 5, gq = i & 31;
+        const int X = blockIdx.x * RS_TW + 4 * gq, Y = blockIdx.y * RS_TH + r;
+        if (X < W && Y < H) { /* the plane rows are padded to a multiple of 16 dwords: a 4-dword store never leaves the row */
+            const uint2 a = s_s8[r * RS_HG + gq], b = s_s8[r * RS_HG + gq + 2];
+            uint4 o;
+            o.x = (a.x & 0xffffu) | (b.x << 16);
+            o.y = (a.x >> 16) | (b.x & 0xffff0000u);
+            o.z = (a.y & 0xffffu) | (b.y << 16);
+            o.w = (a.y >> 16) | (b.y & 0xffff0000u);
+            *(uint4 *)(dst + (size_t)Y * B.refsum_stride + X) = o;
         }
     }
 }
 
-#define SEA_PW (ME_TILE * 16 + 17) /* packed-sum window row: 145 dwords */
+#define SEA_PW (ME_TILE * 16 + 20) /* packed-sum window row: 145 dwords used, padded to 16-byte multiples */
 #define SEA_LIST 64               /* survivors evaluated one by one; more -> dense fallback */
 
 /* SAD of the macroblock against the reference block at window position (cx, cy), computed by
@@ -85,10 +128,9 @@ DEVFN uint32_t me_coop_sad(const uint32_t *s_win, int mbi, int l32, uint32_t c0,
 }
 
 __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ uint32_t s_win[48 * ME_WDW + 4]; /* +4: the realigning fetch may touch one dword past the last row */
-    __shared__ uint32_t s_cur[16 * ME_TILE * 4];
-    __shared__ uint32_t s_p8[41 * SEA_PW];
-    __shared__ uint16_t s_rank[VENC_ME_CANDS];
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[48 * ME_WDW + 4]; /* +4: the realigning fetch may touch one dword past the last row */
+    __shared__ __attribute__((aligned(16))) uint32_t s_cur[16 * ME_TILE * 4];
+    __shared__ __attribute__((aligned(16))) uint32_t s_p8[41 * SEA_PW];
     __shared__ uint32_t s_list[ME_TILE][SEA_LIST];
     __shared__ uint32_t s_cnt[ME_TILE];
 
@@ -99,47 +141,60 @@ __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step 
     int cstride, pw, ph;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
 
-    for (int i = tid; i < VENC_ME_CANDS; i += 256) s_rank[i] = B.me_rank[i];
     if (tid < ME_TILE) s_cnt[tid] = 0;
+    const uint16_t *rank = B.me_rank; /* read straight from global memory: only evaluated candidates need it */
 
+    /* ---- staging, 16 bytes per lane wherever the tile lies inside the frame ---- */
     const bool xin = (x0 - 16 >= 0) && (x0 + ME_TILE * 16 + 16 <= g.cw);
-    for (int i = tid; i < 48 * ME_WDW; i += 256) {
-        int r = i / ME_WDW, d = i - r * ME_WDW;
-        int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
-        int xb = x0 - 16 + 4 * d;
-        const uint8_t *row = ref + (size_t)ry * rstride;
-        uint32_t v;
-        if (xin) {
-            v = *(const uint32_t *)(row + xb);
-        } else {
-            v = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
-                ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
+    if (xin) { /* 48 rows x 10 uint4 */
+        for (int i = tid; i < 480; i += 256) {
+            const int r = i / 10, q = i - r * 10;
+            const int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
+            const uint4 v = *(const uint4 *)(ref + (size_t)ry * rstride + x0 - 16 + 16 * q);
+            *(uint4 *)(s_win + r * ME_WDW + 4 * q) = v;
         }
-        s_win[i] = v;
-    }
-    const bool cur_fast = ((g.w & 3) == 0) && (x0 + ME_TILE * 16 <= g.w);
-    for (int i = tid; i < 16 * ME_TILE * 4; i += 256) {
-        int r = i / (ME_TILE * 4), d = i - r * (ME_TILE * 4);
-        int sy = min(y0 + r, g.h - 1);
-        int xb = x0 + 4 * d;
-        const uint8_t *row = cur + (size_t)sy * cstride;
-        uint32_t v;
-        if (cur_fast) {
-            v = *(const uint32_t *)(row + xb);
-        } else {
-            v = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
-                ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+    } else {
+        for (int i = tid; i < 48 * ME_WDW; i += 256) {
+            int r = i / ME_WDW, d = i - r * ME_WDW;
+            int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
+            int xb = x0 - 16 + 4 * d;
+            const uint8_t *row = ref + (size_t)ry * rstride;
+            s_win[i] = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
+                       ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
         }
-        s_cur[i] = v;
     }
-    /* packed 8x8 block sums of the reference: plane row (y0 + r), plane column x0 + c  (plane origin = picture (-16,-16)) */
+    const bool cur_fast = ((g.w & 15) == 0) && (x0 + ME_TILE * 16 <= g.w);
+    if (cur_fast) { /* 16 rows x 8 uint4 */
+        if (tid < 128) {
+            const int r = tid >> 3, q = tid & 7;
+            const uint4 v = *(const uint4 *)(cur + (size_t)min(y0 + r, g.h - 1) * cstride + x0 + 16 * q);
+            *(uint4 *)(s_cur + r * (ME_TILE * 4) + 4 * q) = v;
+        }
+    } else {
+        for (int i = tid; i < 16 * ME_TILE * 4; i += 256) {
+            int r = i / (ME_TILE * 4), d = i - r * (ME_TILE * 4);
+            int sy = min(y0 + r, g.h - 1);
+            int xb = x0 + 4 * d;
+            const uint8_t *row = cur + (size_t)sy * cstride;
+            s_cur[i] = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
+                       ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+        }
+    }
+    /* packed 8x8 block sums of the reference: plane row (y0 + r), plane column x0 + c (plane origin = picture (-16,-16)) */
     {
         const uint32_t *p8 = B.refsum + (size_t)item * B.refsum_item;
-        const int W = p8_width(g);
-        for (int i = tid; i < 41 * SEA_PW; i += 256) {
-            const int r = i / SEA_PW, c = i - r * SEA_PW;
-            const int X = min(x0 + c, W - 1); /* columns beyond the plane belong to macroblocks beyond the frame */
-            s_p8[i] = p8[(size_t)(y0 + r) * B.refsum_stride + X];
+        if (x0 + SEA_PW <= B.refsum_stride) { /* 41 rows x 37 uint4 */
+            for (int i = tid; i < 41 * 37; i += 256) {
+                const int r = i / 37, q = i - r * 37;
+                const uint4 v = *(const uint4 *)(p8 + (size_t)(y0 + r) * B.refsum_stride + x0 + 4 * q);
+                *(uint4 *)(s_p8 + r * SEA_PW + 4 * q) = v;
+            }
+        } else {
+            const int W = p8_width(g);
+            for (int i = tid; i < 41 * 145; i += 256) {
+                const int r = i / 145, c = i - r * 145;
+                s_p8[r * SEA_PW + c] = p8[(size_t)(y0 + r) * B.refsum_stride + min(x0 + c, W - 1)];
+            }
         }
     }
     __syncthreads();
@@ -186,9 +241,9 @@ __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step 
     /* starting points: zero vector and the macroblock's vector in the previous frame */
     const uint32_t prev = B.mvsad[(size_t)item * g.nmb + my * g.mbw + min(mx, g.mbw - 1)];
     const int pcx = (int)(int8_t)(prev & 255u) + 16, pcy = (int)(int8_t)((prev >> 8) & 255u) + 16;
-    uint32_t best = (me_coop_sad(s_win, mbi, l32, c0, c1, 16, 16) << 11) | s_rank[16 * 33 + 16];
+    uint32_t best = (me_coop_sad(s_win, mbi, l32, c0, c1, 16, 16) << 11) | rank[16 * 33 + 16];
     {
-        const uint32_t k2 = (me_coop_sad(s_win, mbi, l32, c0, c1, pcx, pcy) << 11) | s_rank[pcy * 33 + pcx];
+        const uint32_t k2 = (me_coop_sad(s_win, mbi, l32, c0, c1, pcx, pcy) << 11) | rank[pcy * 33 + pcx];
         best = min(best, k2);
     }
     /* collect the candidates whose bound does not exceed the best SAD so far */
@@ -223,11 +278,11 @@ __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step 
             const bool need = k < cnt && lbv <= (best >> 11);
             const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
             const uint32_t sad = me_coop_sad(s_win, mbi, l32, c0, c1, cx, cy);
-            const uint32_t key = (sad << 11) | s_rank[cy * 33 + cx];
+            const uint32_t key = (sad << 11) | rank[cy * 33 + cx];
             best = min(best, key);
         }
     } else {
-        best = me_dense_half(s_win, s_cur, s_rank, mbi, l32);
+        best = me_dense_half(s_win, s_cur, rank, mbi, l32);
     }
     if (l32 == 0 && mx < g.mbw) {
         uint32_t cand = B.me_cand[best & 2047u];
