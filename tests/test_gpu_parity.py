@@ -166,13 +166,13 @@ def test_resident_full_size_roundtrip(venc, orc):
     assert hashes[0] == hashes[1]
 
 
-def _me_run(venc, frames, w, h, dense):
+def _me_run(venc, frames, w, h, mode):
     import os
-    os.environ["VENC_ME_DENSE"] = "1" if dense else "0"
+    os.environ["VENC_ME"] = mode
     try:
         eng = venc.Engine(w, h, qp=26, n_slices=4, max_items=1, in_slots=2, out_slots=2)
     finally:
-        os.environ.pop("VENC_ME_DENSE", None)
+        os.environ.pop("VENC_ME", None)
     out = []
     for t, (y, u, v) in enumerate(frames):
         eng.upload(t % 2, y, u, v)
@@ -205,13 +205,15 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
         yy, xx = np.mgrid[0:h, 0:w]
         frames = [((((xx + 2 * t) // 4) % 2) * 200 + 20).astype(np.uint8) for t in range(n)]
         frames = [(f, np.full((h // 2, w // 2), 128, np.uint8), np.full((h // 2, w // 2), 128, np.uint8)) for f in frames]
-    a = _me_run(venc, frames, w, h, dense=False)
-    b = _me_run(venc, frames, w, h, dense=True)
+    a = _me_run(venc, frames, w, h, "tile")      # default: sums built in-kernel + k_me_fix
+    b = _me_run(venc, frames, w, h, "dense")     # exhaustive
+    c = _me_run(venc, frames, w, h, "plane")     # sums from the k_refsum plane, in-kernel dense fallback
     enc = orc.Encoder(w, h, qp=26, n_slices=4, keyint=100, threads=8)
     for t, (y, u, v) in enumerate(frames):
         enc.encode(y, u, v)
-        assert np.array_equal(a[t][0], b[t][0]), "%s frame %d: pruned != exhaustive" % (kind, t)
-        assert a[t][1] == b[t][1]
+        assert np.array_equal(a[t][0], b[t][0]), "%s frame %d: pruned (tile) != exhaustive" % (kind, t)
+        assert np.array_equal(c[t][0], b[t][0]), "%s frame %d: pruned (plane) != exhaustive" % (kind, t)
+        assert a[t][1] == b[t][1] and c[t][1] == b[t][1]
         if t:
             mv = np.stack([(a[t][0] & 0xff).astype(np.int8), ((a[t][0] >> 8) & 0xff).astype(np.int8)], axis=1)
             assert np.array_equal(mv, enc.mv()), "%s frame %d: mv != oracle" % (kind, t)
@@ -221,7 +223,12 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
 def test_reference_block_sums_plane(venc):
     """k_refsum: P8(x,y) = S8(x,y) | S8(x+8,y) << 16 over the edge-replicated reconstruction."""
     w, h = 352, 288
-    eng = venc.Engine(w, h, qp=30, n_slices=2, max_items=1, in_slots=1, out_slots=1)
+    import os
+    os.environ["VENC_ME"] = "plane"
+    try:
+        eng = venc.Engine(w, h, qp=30, n_slices=2, max_items=1, in_slots=1, out_slots=1)
+    finally:
+        os.environ.pop("VENC_ME", None)
     eng.upload(0, *venc.synth_frame(w, h, 0, 9))
     eng.encode_step([0], [0], True, 0, [0])
     eng.sync()

@@ -258,7 +258,7 @@ class Engine:
         shapes = {0: ((self.nmb,), np.uint32), 1: ((self.nmb, 27, 16), np.int16), 2: ((self.nmb, 32), np.uint8),
                   3: ((self.nmb,), np.uint32), 4: ((ch, cw), np.uint8), 5: ((ch // 2, cw // 2), np.uint8),
                   6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32),
-                  8: ((ch + 25, (cw + 32) & ~15), np.uint32)}
+                  8: ((ch + 25, (cw + 32) & ~15), np.uint32), 9: ((self.nmb,), np.uint8), 10: ((self.nmb,), np.uint8)}
         shape, dt = shapes[what]
         a = np.empty(shape, dt)
         self._ok(self.L.venc_debug_read(self.h, what, item, a.ctypes.data, a.nbytes), "venc_debug_read")

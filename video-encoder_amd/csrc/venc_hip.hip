@@ -18,6 +18,7 @@
 #include "../../include/venc_hip.h"
 #include "venc_kernels.hip"
 #include "venc_me.hip"
+#include "venc_me2.hip"
 #include "venc_synth.h"
 
 static thread_local char g_err[512] = "";
@@ -38,7 +39,11 @@ struct venc_ctx {
     venc_config cfg;
     venc_geom g;
     venc_bufs b;
-    hipStream_t stream;
+    hipStream_t stream;  /* main chain: ingest, k_me, k_me_fix, k_inter / k_intra */
+    hipStream_t stream2; /* entropy chain of the same step: k_cavlc, k_scan, k_pack -- overlaps the next step's main chain */
+    hipEvent_t ev_main[2], ev_side[2]; /* per parity: main chain done / k_cavlc done with the parity's buffers */
+    int side_used[2];
+    int overlap;
     hipEvent_t ev[VENC_EVENTS];
     int ev_next;
     int parity;
@@ -51,7 +56,8 @@ struct venc_ctx {
     uint16_t *d_rank, *d_cand;
     int intra_waves;
     int steps_done;
-    int me_dense; /* VENC_ME_DENSE=1: exhaustive k_me_dense instead of successive elimination */
+    int me_mode;  /* 0 tile (default): successive elimination, sums built in-kernel; 1 plane: sums from k_refsum;
+                     2 dense: exhaustive search.  Env VENC_ME=tile|plane|dense (VENC_ME_DENSE=1 = dense). */
     /* optional per-kernel HIP-event timing (venc_profile) */
     int prof_on;
     hipEvent_t *prof_ev; /* pairs */
@@ -59,17 +65,17 @@ struct venc_ctx {
     int prof_n, prof_cap;
 };
 
-enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_COUNT };
-static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum"};
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_COUNT };
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix"};
 
-static void prof_begin(venc_ctx *c, int kid) {
+static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
     if (!c->prof_on || c->prof_n >= c->prof_cap) return;
     c->prof_kid[c->prof_n] = kid;
-    (void)hipEventRecord(c->prof_ev[2 * c->prof_n], c->stream);
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
 }
-static void prof_end(venc_ctx *c) {
+static void prof_end(venc_ctx *c, hipStream_t st) {
     if (!c->prof_on || c->prof_n >= c->prof_cap) return;
-    (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], c->stream);
+    (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
     c->prof_n++;
 }
 
@@ -102,8 +108,14 @@ extern "C" void venc_close(venc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (int i = 0; i < VENC_EVENTS; i++)
         if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_main[i]) (void)hipEventDestroy(c->ev_main[i]);
+        if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
+    }
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     (void)hipFree(c->d_in);
     (void)hipFree(c->b.recon);
     (void)hipFree(c->b.mvsad);
@@ -113,6 +125,10 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.mbnbits);
     (void)hipFree(c->b.mboff);
     (void)hipFree(c->b.refsum);
+    (void)hipFree(c->b.me_flag);
+    (void)hipFree(c->b.me_cnt);
+    (void)hipFree(c->b.fix_count);
+    (void)hipFree(c->b.fix_list);
     (void)hipFree(c->d_slice);
     (void)hipFree(c->d_slice_rows);
     (void)hipFree(c->d_row_slice);
@@ -187,7 +203,13 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     } while (0)
 
     OPEN_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     for (int i = 0; i < VENC_EVENTS; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        OPEN_OK(hipEventCreateWithFlags(&c->ev_main[i], hipEventDisableTiming));
+        OPEN_OK(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
+    }
+    c->overlap = !(getenv("VENC_NO_OVERLAP") && atoi(getenv("VENC_NO_OVERLAP")) != 0);
 
     /* slice bands: the first (mbh % n) bands get one extra MB row */
     int rows[VENC_MAX_SLICES + 1];
@@ -238,11 +260,13 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     b.recon_frame_bytes = (size_t)g.cw * g.ch * 3 / 2;
     OPEN_OK(hipMalloc(&b.recon, 2 * G * b.recon_frame_bytes));
     OPEN_OK(hipMemset(b.recon, 128, 2 * G * b.recon_frame_bytes));
-    OPEN_OK(hipMalloc(&b.mvsad, G * nmb * 4));
-    OPEN_OK(hipMemset(b.mvsad, 0, G * nmb * 4));
-    OPEN_OK(hipMalloc(&b.levels, G * nmb * VENC_MB_COEFS * 2));
-    OPEN_OK(hipMalloc(&b.mbinfo, G * nmb * sizeof(venc_mbinfo)));
-    OPEN_OK(hipMemset(b.mbinfo, 0, G * nmb * sizeof(venc_mbinfo)));
+    /* mvsad, levels and mbinfo exist twice (by frame parity): the entropy chain of step t reads
+     * parity p while the main chain of step t+1 already writes parity p^1 */
+    OPEN_OK(hipMalloc(&b.mvsad, 2 * G * nmb * 4));
+    OPEN_OK(hipMemset(b.mvsad, 0, 2 * G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.levels, 2 * G * nmb * VENC_MB_COEFS * 2));
+    OPEN_OK(hipMalloc(&b.mbinfo, 2 * G * nmb * sizeof(venc_mbinfo)));
+    OPEN_OK(hipMemset(b.mbinfo, 0, 2 * G * nmb * sizeof(venc_mbinfo)));
     OPEN_OK(hipMalloc(&b.mbbits, G * nmb * VENC_MB_WORDS * 4));
     OPEN_OK(hipMalloc(&b.mbnbits, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
@@ -250,7 +274,20 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
     OPEN_OK(hipMalloc(&b.refsum, G * b.refsum_item * 4));
     OPEN_OK(hipMemset(b.refsum, 0, G * b.refsum_item * 4));
-    c->me_dense = getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0;
+    {
+        const char *m = getenv("VENC_ME");
+        c->me_mode = 0;
+        if (m && !strcmp(m, "plane")) c->me_mode = 1;
+        if (m && !strcmp(m, "dense")) c->me_mode = 2;
+        if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
+    }
+    OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
+    OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
+    OPEN_OK(hipMalloc(&b.fix_count, G * 4));
+    OPEN_OK(hipMemset(b.fix_count, 0, G * 4));
+    OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.me_cnt, G * nmb));
+    OPEN_OK(hipMemset(b.me_cnt, 0, G * nmb));
     OPEN_OK(hipMalloc(&c->d_slice, G * g.n_slices * sizeof(venc_slice_out)));
     b.slice_first_row = c->d_slice_rows;
     b.row_slice = c->d_row_slice;
@@ -375,38 +412,63 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         S.idr_id[i] = idr_ids ? idr_ids[i] : 0;
     }
     const venc_geom &g = c->g;
-    const venc_bufs &b = c->b;
+    const int p = c->parity;
+    const size_t GN = (size_t)c->b.max_items * g.nmb;
+    venc_bufs b = c->b;
+    b.mvsad = c->b.mvsad + (size_t)p * GN;
+    b.mvsad_prev = c->b.mvsad + (size_t)(p ^ 1) * GN;
+    b.levels = c->b.levels + (size_t)p * GN * VENC_MB_COEFS;
+    b.mbinfo = c->b.mbinfo + (size_t)p * GN;
+    hipStream_t s1 = c->stream, s2 = c->overlap ? c->stream2 : c->stream;
+    if (c->overlap && c->side_used[p]) HIP_OK(hipStreamWaitEvent(s1, c->ev_side[p], 0)); /* parity buffers free again */
     if (is_idr) {
-        prof_begin(c, KID_INTRA);
-        hipLaunchKernelGGL(k_intra, dim3(g.n_slices, 1, n_items), dim3(64 * c->intra_waves), 0, c->stream, g, b, S);
-        prof_end(c);
+        prof_begin(c, KID_INTRA, s1);
+        hipLaunchKernelGGL(k_intra, dim3(g.n_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
+        prof_end(c, s1);
     } else {
-        prof_begin(c, KID_ME);
-        if (c->me_dense)
-            hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
+        if (c->me_mode == 0) HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
+        prof_begin(c, KID_ME, s1);
+        if (c->me_mode == 2)
+            hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, s1, g, b, S);
+        else if (c->me_mode == 1)
+            hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, s1, g, b, S);
         else
-            hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, c->stream, g, b, S);
-        prof_end(c);
-        prof_begin(c, KID_INTER);
-        hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, c->stream, g, b, S);
-        prof_end(c);
+            hipLaunchKernelGGL(k_me_tile, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (g.mbh + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
+                               s1, g, b, S);
+        prof_end(c, s1);
+        if (c->me_mode == 0) {
+            prof_begin(c, KID_MEFIX, s1);
+            hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S);
+            prof_end(c, s1);
+        }
+        prof_begin(c, KID_INTER, s1);
+        hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
+        prof_end(c, s1);
     }
-    if (!c->me_dense) { /* block sums of the frame just reconstructed = reference of the next P step */
-        prof_begin(c, KID_REFSUM);
+    if (c->me_mode == 1) { /* block sums of the frame just reconstructed = reference of the next P step */
+        prof_begin(c, KID_REFSUM, s1);
         hipLaunchKernelGGL(k_refsum, dim3((g.cw + 17 + RS_TW - 1) / RS_TW, (g.ch + 25 + RS_TH - 1) / RS_TH, n_items), dim3(256), 0,
-                           c->stream, g, b, S);
-        prof_end(c);
+                           s1, g, b, S);
+        prof_end(c, s1);
     }
-    prof_begin(c, KID_CAVLC);
-    hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, c->stream, g, b, S);
-    prof_end(c);
-    prof_begin(c, KID_SCAN);
-    hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, c->stream, g, b, S, c->d_slice);
-    prof_end(c);
-    prof_begin(c, KID_PACK);
-    hipLaunchKernelGGL(k_pack, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, c->stream, g, b, S,
+    if (c->overlap) {
+        HIP_OK(hipEventRecord(c->ev_main[p], s1));
+        HIP_OK(hipStreamWaitEvent(s2, c->ev_main[p], 0));
+    }
+    prof_begin(c, KID_CAVLC, s2);
+    hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
+    prof_end(c, s2);
+    if (c->overlap) {
+        HIP_OK(hipEventRecord(c->ev_side[p], s2));
+        c->side_used[p] = 1;
+    }
+    prof_begin(c, KID_SCAN, s2);
+    hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, s2, g, b, S, c->d_slice);
+    prof_end(c, s2);
+    prof_begin(c, KID_PACK, s2);
+    hipLaunchKernelGGL(k_pack, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S,
                        (const venc_slice_out *)c->d_slice);
-    prof_end(c);
+    prof_end(c, s2);
     HIP_OK(hipGetLastError());
     c->parity ^= 1;
     c->steps_done++;
@@ -415,7 +477,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
 
 extern "C" int venc_mark(venc_ctx *c) {
     const int t = c->ev_next;
-    HIP_OK(hipEventRecord(c->ev[t % VENC_EVENTS], c->stream));
+    HIP_OK(hipEventRecord(c->ev[t % VENC_EVENTS], c->overlap ? c->stream2 : c->stream));
     c->ev_next++;
     return t;
 }
@@ -429,6 +491,7 @@ extern "C" int venc_wait(venc_ctx *c, int ticket) {
 }
 extern "C" int venc_sync(venc_ctx *c) {
     HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream2));
     return 0;
 }
 
@@ -458,21 +521,25 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
     }
     HIP_OK(hipSetDevice(c->cfg.device));
     HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream2));
     const venc_geom &g = c->g;
     const size_t nmb = (size_t)g.nmb;
     const void *src = NULL;
     size_t n = 0;
     const int last_parity = c->parity ^ 1;
+    const size_t lp_off = (size_t)last_parity * c->b.max_items; /* parity-indexed intermediates of the last step */
     const uint8_t *rec = c->b.recon + (size_t)(last_parity * c->b.max_items + item) * c->b.recon_frame_bytes;
     switch (what) {
-        case 0: src = c->b.mvsad + item * nmb, n = nmb * 4; break;
-        case 1: src = c->b.levels + item * nmb * VENC_MB_COEFS, n = nmb * VENC_MB_COEFS * 2; break;
-        case 2: src = c->b.mbinfo + item * nmb, n = nmb * sizeof(venc_mbinfo); break;
+        case 0: src = c->b.mvsad + (lp_off + item) * nmb, n = nmb * 4; break;
+        case 1: src = c->b.levels + (lp_off + item) * nmb * VENC_MB_COEFS, n = nmb * VENC_MB_COEFS * 2; break;
+        case 2: src = c->b.mbinfo + (lp_off + item) * nmb, n = nmb * sizeof(venc_mbinfo); break;
         case 3: src = c->b.mbnbits + item * nmb, n = nmb * 4; break;
         case 4: src = rec, n = (size_t)g.cw * g.ch; break;
         case 5: src = rec + (size_t)g.cw * g.ch, n = (size_t)g.cw * g.ch / 4; break;
         case 6: src = rec + (size_t)g.cw * g.ch * 5 / 4, n = (size_t)g.cw * g.ch / 4; break;
         case 7: src = c->b.mboff + item * nmb, n = nmb * 4; break;
+        case 9: src = c->b.me_cnt + item * nmb, n = nmb; break;
+        case 10: src = c->b.me_flag + item * nmb, n = nmb; break;
         case 8: src = c->b.refsum + item * c->b.refsum_item, n = c->b.refsum_item * 4; break;
         default: SET_ERR("venc_debug_read: unknown selector %d", what); return -1;
     }
@@ -481,6 +548,28 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         return -1;
     }
     HIP_OK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+    if (what == 1) {
+        /* the kernels do not write blocks that hold no level (and k_cavlc never reads them):
+         * present the record with those blocks zeroed, as the level record is defined */
+        venc_mbinfo *mi = (venc_mbinfo *)malloc(nmb * sizeof(venc_mbinfo));
+        if (!mi) return -1;
+        HIP_OK(hipMemcpy(mi, c->b.mbinfo + (lp_off + item) * nmb, nmb * sizeof(venc_mbinfo), hipMemcpyDeviceToHost));
+        int16_t *lv = (int16_t *)dst;
+        static const int blk_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+        for (size_t m = 0; m < nmb; m++) {
+            int16_t *r = lv + m * VENC_MB_COEFS;
+            const int i16 = mi[m].flags & 1, cbpc = mi[m].cbp >> 4;
+            for (int b = 0; b < 16; b++)
+                if (mi[m].nnz[blk_raster[b]] == 0) memset(r + b * 16, 0, 32);
+            if (!i16) memset(r + 16 * 16, 0, 32);
+            for (int k = 0; k < 8; k++)
+                if (mi[m].nnz[16 + k] == 0) memset(r + (19 + k) * 16, 0, 32);
+            memset(r + 17 * 16 + 4, 0, 24);
+            memset(r + 18 * 16 + 4, 0, 24);
+            (void)cbpc;
+        }
+        free(mi);
+    }
     return 0;
 }
 
@@ -503,6 +592,7 @@ extern "C" const char *venc_profile_name(int kid) { return kid >= 0 && kid < KID
 /* sums the recorded launches per kernel (after a stream sync) and resets the log */
 extern "C" int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches) {
     HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream2));
     for (int k = 0; k < KID_COUNT; k++) ms_sum[k] = 0.0, launches[k] = 0;
     for (int i = 0; i < c->prof_n; i++) {
         float ms = 0.f;

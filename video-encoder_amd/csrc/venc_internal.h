@@ -75,6 +75,7 @@ typedef struct {
     size_t recon_frame_bytes;
     int max_items;
     uint32_t *mvsad;
+    const uint32_t *mvsad_prev; /* vectors of the previous step (temporal predictor of the motion search) */
     int16_t *levels;
     venc_mbinfo *mbinfo;
     uint32_t *mbbits;
@@ -87,6 +88,10 @@ typedef struct {
     uint32_t *refsum;           /* [G][p8 rows][refsum_stride] packed 8x8 block sums of the reference (venc_me.hip) */
     int refsum_stride;          /* dwords per row */
     size_t refsum_item;         /* dwords per item */
+    uint8_t *me_flag;           /* [G][nmb] 1 = k_me_tile left this macroblock to k_me_fix */
+    uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zeroed before k_me_tile) */
+    uint32_t *fix_list;         /* [G][nmb] their indices */
+    uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
     uint8_t *out_base;          /* device view of the pinned output pool */
     size_t out_slot_bytes;
     uint32_t out_data_off;      /* offset of data[] inside a slot */

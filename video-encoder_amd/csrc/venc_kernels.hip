@@ -196,8 +196,8 @@ struct mb_lane_out {
     int nnz;
 };
 
-DEVFN void mb_code(int lane, bool i16, bool intra, const int cur[16], const int pred[16], const venc_geom &g,
-                   mb_lane_out &o) {
+template <bool i16, bool intra>
+DEVFN void mb_code(int lane, const int cur[16], const int pred[16], const venc_geom &g, mb_lane_out &o) {
     const int l32 = lane & 31, base = lane & 32;
     const bool luma = l32 < 16;
     const bool dc_sep = luma ? i16 : true;
@@ -221,24 +221,27 @@ DEVFN void mb_code(int lane, bool i16, bool intra, const int cur[16], const int 
         oy = by;
         ox = bx;
     }
-    int ydc = 0;
+    int dcl_luma = 0, d0_luma = 0;
+    if (i16) { /* compile-time: inter macroblocks carry no separate luma DC */
+        int ydc = 0;
 #pragma unroll
-    for (int qi = 0; qi < 16; qi++) {
-        int qy = qi >> 2, qx = qi & 3;
-        int v = __shfl(w[0], base | blk_of(qx, qy));
-        int neg = ((0xA6C0 >> (4 * oy + qy)) ^ (0xA6C0 >> (4 * ox + qx))) & 1;
-        ydc += neg ? -v : v;
-    }
-    int dcl_luma = venc_quant_luma_dc(ydc, &g.ql);
-    int fdc = 0;
+        for (int qi = 0; qi < 16; qi++) {
+            int qy = qi >> 2, qx = qi & 3;
+            int v = __shfl(w[0], base | blk_of(qx, qy));
+            int neg = ((0xA6C0 >> (4 * oy + qy)) ^ (0xA6C0 >> (4 * ox + qx))) & 1;
+            ydc += neg ? -v : v;
+        }
+        dcl_luma = venc_quant_luma_dc(ydc, &g.ql);
+        int fdc = 0;
 #pragma unroll
-    for (int qi = 0; qi < 16; qi++) {
-        int qy = qi >> 2, qx = qi & 3;
-        int v = __shfl(dcl_luma, base | blk_of(qx, qy));
-        int neg = ((0xA6C0 >> (4 * oy + qy)) ^ (0xA6C0 >> (4 * ox + qx))) & 1;
-        fdc += neg ? -v : v;
+        for (int qi = 0; qi < 16; qi++) {
+            int qy = qi >> 2, qx = qi & 3;
+            int v = __shfl(dcl_luma, base | blk_of(qx, qy));
+            int neg = ((0xA6C0 >> (4 * oy + qy)) ^ (0xA6C0 >> (4 * ox + qx))) & 1;
+            fdc += neg ? -v : v;
+        }
+        d0_luma = venc_dequant_luma_dc(fdc, &g.ql);
     }
-    int d0_luma = venc_dequant_luma_dc(fdc, &g.ql);
 
     /* ---- chroma DC: 2x2 over the four lanes of a plane */
     const int cbase = base | (l32 & 28), ck = l32 & 3;
@@ -289,12 +292,16 @@ DEVFN void mb_store(int l32, bool valid, const mb_lane_out &o, int16_t *lv_mb, v
     if (!valid || l32 >= 24) return;
     const bool luma = l32 < 16;
     const int slot = luma ? l32 : 19 + (l32 - 16);
-    uint32_t p[8];
+    /* all-zero blocks are not written: k_cavlc reads a block's levels only when its nnz is non-zero
+     * (most blocks of a P frame are empty, and the level record is the largest stream of the path) */
+    if (o.nnz) {
+        uint32_t p[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) p[i] = ((uint32_t)o.lv[2 * i] & 0xffffu) | ((uint32_t)o.lv[2 * i + 1] << 16);
-    uint4 *dst = (uint4 *)(lv_mb + slot * 16);
-    dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
-    dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+        for (int i = 0; i < 8; i++) p[i] = ((uint32_t)o.lv[2 * i] & 0xffffu) | ((uint32_t)o.lv[2 * i + 1] << 16);
+        uint4 *dst = (uint4 *)(lv_mb + slot * 16);
+        dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
+        dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+    }
     const int nidx = luma ? blk_y(l32) * 4 + blk_x(l32) : l32;
     info->nnz[nidx] = (uint8_t)o.nnz;
 #pragma unroll
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
                                 xf * yf * smp[y + 1][x + 1] + 32) >> 6;
     }
     mb_lane_out o;
-    mb_code(lane, false, false, c, p, g, o);
+    mb_code<false, false>(lane, c, p, g, o);
 
     int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
@@ -409,12 +416,11 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
     /* chroma DC records (slots 17, 18) and the empty luma-DC slot 16 */
     int dc0 = __shfl(o.dclv, base | (l32 & 28) | 0), dc1 = __shfl(o.dclv, base | (l32 & 28) | 1);
     int dc2 = __shfl(o.dclv, base | (l32 & 28) | 2), dc3 = __shfl(o.dclv, base | (l32 & 28) | 3);
-    if (valid && (l32 == 16 || l32 == 20 || l32 == 24)) {
-        uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : l32 == 20 ? 18 : 16) * 16);
-        uint32_t a = l32 == 24 ? 0u : (((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16));
-        uint32_t b = l32 == 24 ? 0u : (((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16));
+    if (valid && (l32 == 16 || l32 == 20)) { /* slot 16 (Intra16x16 luma DC) is never read for inter macroblocks */
+        uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
+        uint32_t a = ((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16);
+        uint32_t b = ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16);
         dst[0] = make_uint4(a, b, 0, 0);
-        dst[1] = make_uint4(0, 0, 0, 0);
     }
     /* coded_block_pattern from wave ballots */
     const unsigned long long bal_nz = __ballot(o.nnz > 0);
@@ -501,7 +507,7 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                         p[4 * y + x] = pred;
                     }
                 mb_lane_out o;
-                mb_code(lane, true, true, c, p, g, o);
+                mb_code<true, true>(lane, c, p, g, o);
 
                 int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
                 venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
@@ -522,7 +528,6 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                     uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
                     dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16),
                                         ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
-                    dst[1] = make_uint4(0, 0, 0, 0);
                 }
                 const uint32_t hnz = (uint32_t)__ballot(o.nnz > 0), hdc = (uint32_t)__ballot(o.dclv != 0);
                 if (lane == 0) {
@@ -650,7 +655,18 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     venc_bs_init(&bs, s_priv + (team * 32 + l32) * VENC_LANE_WORDS);
     if (coded) {
         int c[16];
-        load_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16, c);
+        /* AC / luma blocks with nnz = 0 were not written by the transform kernels */
+        bool empty = false;
+        if (l32 >= 2 && l32 < 18)
+            empty = info->nnz[blk_y(l32 - 2) * 4 + blk_x(l32 - 2)] == 0;
+        else if (l32 >= 20 && l32 < 28)
+            empty = info->nnz[16 + (l32 - 20)] == 0;
+        if (empty) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) c[i] = 0;
+        } else {
+            load_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16, c);
+        }
         venc_cavlc_block(&bs, c, first, maxc, nC);
     }
     if (l32 == 0 && valid) {

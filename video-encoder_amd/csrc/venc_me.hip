@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step 
     }
 
     /* starting points: zero vector and the macroblock's vector in the previous frame */
-    const uint32_t prev = B.mvsad[(size_t)item * g.nmb + my * g.mbw + min(mx, g.mbw - 1)];
+    const uint32_t prev = B.mvsad_prev[(size_t)item * g.nmb + my * g.mbw + min(mx, g.mbw - 1)];
     const int pcx = (int)(int8_t)(prev & 255u) + 16, pcy = (int)(int8_t)((prev >> 8) & 255u) + 16;
     uint32_t best = (me_coop_sad(s_win, mbi, l32, c0, c1, 16, 16) << 11) | rank[16 * 33 + 16];
     {

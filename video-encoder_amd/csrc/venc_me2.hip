@@ -1,0 +1,359 @@
+/*
+ * venc_me2.hip -- successive-elimination motion search with the block sums built
+ * inside the kernel (no sums plane, no extra pass over the reference).
+ *
+ * Why: with the sums taken from a precomputed plane (venc_me.hip) every 8-macroblock
+ * block staged 34 KB (4.2 KB per macroblock, 8x the algorithmic 512 B) and the kernel ran
+ * at the L2->LDS fill rate.  Here one block owns an 8 x 2 macroblock tile, stages only the
+ * pixels it needs (64 x 160 reference window + 32 x 128 current tile: 0.9 KB per
+ * macroblock) and derives the 8x8 block sums of every window position from the LDS copy:
+ *   P1  horizontal 8-sums with v_qsad_pk_u16_u8 against zero (4 sliding 4-byte sums per
+ *       instruction, two of them added), packed u16x4
+ *   P2  vertical 8-sums by a sliding window (packed u16 adds)
+ *   P3  lower bounds LB(c) = sum_k |S8cur_k - S8ref_k(c)| for all 1089 candidates: every
+ *       lane owns one displacement column, reads each sums row once, 2 v_sad_u16 per candidate
+ *   P4  SAD only where LB <= best SAD so far (start: zero vector and last frame's vector)
+ * The result equals the exhaustive search bit for bit (see venc_me.hip for the argument).
+ * Macroblocks with more than SEA_LIST surviving candidates (flat content) are flagged and
+ * redone by k_me_fix with the exhaustive half-wave search.
+ */
+
+#define T2_MBX 8
+#define T2_MBY 2
+#define T2_WR (T2_MBY * 16 + 32) /* window rows: 64 */
+#define T2_WD 42                 /* window row stride in dwords: 160 pixels + 8 bytes of zero padding */
+#define T2_HG 39                 /* groups of 4 columns with horizontal sums: columns 0..155 (0..152 used) */
+#define T2_SR (T2_MBY * 16 + 25) /* rows of block sums: 57 */
+#define T2_SU (T2_HG * 4)        /* sums row stride in u16: 156 */
+
+DEVFN uint2 pk4_add(uint2 a, uint2 b) { return make_uint2(a.x + b.x, a.y + b.y); }
+DEVFN uint2 pk4_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y); }
+
+/* ---- half-wave (32-lane) reductions on the DPP network: 4 row_shr steps inside each row of 16
+ * lanes, one row_bcast:15 into rows 1 and 3, then the totals are read from lanes 31 and 63.
+ * About 8 VALU/SALU instructions and no LDS traffic (ds_bpermute butterflies cost ~5 LDS round trips). */
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+template <int CTRL, int ROWMASK>
+DEVFN uint32_t dpp_fetch(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+DEVFN uint32_t half_sum32(uint32_t v, int lane) {
+    v += dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0u);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return lane < 32 ? lo : hi;
+}
+DEVFN uint32_t half_min32(uint32_t v, int lane) {
+    v = min(v, dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0xffffffffu));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return lane < 32 ? lo : hi;
+}
+
+/* SAD of one macroblock at window position (col0 + cx, row0 + cy), 8 pixels per lane of a half-wave */
+DEVFN uint32_t me2_coop_sad(const uint32_t *s_win, int col0, int row0, int lane, uint32_t c0, uint32_t c1, int cx, int cy) {
+    const int l32 = lane & 31;
+    const int row = l32 >> 1, hx = (l32 & 1) * 8;
+    const int boff = col0 + cx + hx;
+    const uint32_t *p = s_win + (row0 + cy + row) * T2_WD + (boff >> 2);
+    const uint32_t sh = (uint32_t)(boff & 3);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+    uint32_t a = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d1, d0, sh), c0, 0u);
+    a = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(d2, d1, sh), c1, a);
+    return half_sum32(a, lane);
+}
+
+__global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_win[T2_WR * T2_WD];
+    __shared__ __attribute__((aligned(16))) uint2 s_h8[T2_WR * T2_HG]; /* later reused for the current tile */
+    __shared__ __attribute__((aligned(16))) uint2 s_s8[T2_SR * T2_HG];
+    __shared__ uint32_t s_list[T2_MBX * T2_MBY][SEA_LIST];
+    __shared__ uint32_t s_cnt[T2_MBX * T2_MBY];
+    __shared__ uint16_t s_rank[VENC_ME_CANDS + 1];
+
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int x0 = blockIdx.x * T2_MBX * 16, y0 = blockIdx.y * T2_MBY * 16;
+    int rstride, cstride, pw, ph;
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+    for (int i = tid; i < VENC_ME_CANDS; i += 512) s_rank[i] = B.me_rank[i];
+    const uint16_t *rank = s_rank;
+
+    if (tid < T2_MBX * T2_MBY) s_cnt[tid] = 0;
+    /* ---- P0: reference window, rows y0-16 .. y0+47, columns x0-16 .. x0+143 (+8 zero bytes) ---- */
+    const bool xin = (x0 - 16 >= 0) && (x0 + T2_MBX * 16 + 16 <= g.cw);
+    if (xin) {
+        for (int i = tid; i < T2_WR * 10; i += 512) {
+            const int r = i / 10, q = i - r * 10;
+            const int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
+            const uint4 v = *(const uint4 *)(ref + (size_t)ry * rstride + x0 - 16 + 16 * q);
+            uint32_t *d = s_win + r * T2_WD + 4 * q;
+            *(uint2 *)d = make_uint2(v.x, v.y); /* row stride is 8-byte aligned only */
+            *(uint2 *)(d + 2) = make_uint2(v.z, v.w);
+        }
+    } else {
+        for (int i = tid; i < T2_WR * 40; i += 512) {
+            const int r = i / 40, d = i - r * 40;
+            const int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
+            const int xb = x0 - 16 + 4 * d;
+            const uint8_t *row = ref + (size_t)ry * rstride;
+            s_win[r * T2_WD + d] = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
+                                   ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) |
+                                   ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
+        }
+    }
+    if (tid < T2_WR) {
+        s_win[tid * T2_WD + 40] = 0;
+        s_win[tid * T2_WD + 41] = 0;
+    }
+    __syncthreads();
+    /* ---- P1: horizontal 8-sums, four columns per item ---- */
+    for (int i = tid; i < T2_WR * T2_HG; i += 512) {
+        const int r = i / T2_HG, q = i - r * T2_HG;
+        const uint32_t *p = s_win + r * T2_WD + q;
+        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+        const unsigned long long a = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d1 << 32) | d0, 0u, 0ull);
+        const unsigned long long b = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d2 << 32) | d1, 0u, 0ull);
+        s_h8[i] = pk4_add(make_uint2((uint32_t)a, (uint32_t)(a >> 32)), make_uint2((uint32_t)b, (uint32_t)(b >> 32)));
+    }
+    __syncthreads();
+    /* ---- P2: vertical 8-sums: 8 segments of up to 8 rows x 39 column groups ---- */
+    if (tid < 8 * T2_HG) {
+        const int seg = tid / T2_HG, q = tid - seg * T2_HG;
+        const int r0 = seg * 8;
+        const uint2 *col = s_h8 + r0 * T2_HG + q;
+        uint2 acc = col[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) acc = pk4_add(acc, col[k * T2_HG]);
+        s_s8[r0 * T2_HG + q] = acc;
+#pragma unroll
+        for (int k = 1; k < 8; k++) {
+            if (r0 + k < T2_SR) {
+                acc = pk4_sub(pk4_add(acc, col[(k + 7) * T2_HG]), col[(k - 1) * T2_HG]);
+                s_s8[(r0 + k) * T2_HG + q] = acc;
+            }
+        }
+    }
+    __syncthreads();
+    /* ---- current tile (32 rows x 128 bytes) into the space of s_h8 ---- */
+    uint32_t *s_cur = (uint32_t *)s_h8;
+    const bool cur_fast = ((g.w & 15) == 0) && (x0 + T2_MBX * 16 <= g.w);
+    if (cur_fast) {
+        if (tid < 256) {
+            const int r = tid >> 3, q = tid & 7;
+            const uint4 v = *(const uint4 *)(cur + (size_t)min(y0 + r, g.h - 1) * cstride + x0 + 16 * q);
+            *(uint4 *)(s_cur + r * 32 + 4 * q) = v;
+        }
+    } else {
+        for (int i = tid; i < 32 * 32; i += 512) {
+            const int r = i >> 5, d = i & 31;
+            const int xb = x0 + 4 * d;
+            const uint8_t *row = cur + (size_t)min(y0 + r, g.h - 1) * cstride;
+            s_cur[i] = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
+                       ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+        }
+    }
+    __syncthreads();
+
+    /* ---- per macroblock: one half-wave ---- */
+    const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
+    const int hw = tid >> 5;
+    const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
+    const int mx = blockIdx.x * T2_MBX + mbx, my = blockIdx.y * T2_MBY + mby;
+    const bool mb_valid = mx < g.mbw && my < g.mbh;
+    const int col0 = mbx * 16, row0 = mby * 16;
+
+    const uint32_t c0 = s_cur[(row0 + (l32 >> 1)) * 32 + mbx * 4 + (l32 & 1) * 2];
+    const uint32_t c1 = s_cur[(row0 + (l32 >> 1)) * 32 + mbx * 4 + (l32 & 1) * 2 + 1];
+    uint32_t part = __builtin_amdgcn_sad_u8(c0, 0u, 0u);
+    part = __builtin_amdgcn_sad_u8(c1, 0u, part);
+    part += (uint32_t)__shfl_xor((int)part, 2);
+    part += (uint32_t)__shfl_xor((int)part, 4);
+    part += (uint32_t)__shfl_xor((int)part, 8);
+    const uint32_t q00 = (uint32_t)__shfl((int)part, hbase | 0), q01 = (uint32_t)__shfl((int)part, hbase | 1);
+    const uint32_t q10 = (uint32_t)__shfl((int)part, hbase | 16), q11 = (uint32_t)__shfl((int)part, hbase | 17);
+    const uint32_t ctop = q00 | (q01 << 16), cbot = q10 | (q11 << 16);
+
+    /* ---- P3: lower bounds.  Lane = window column cx = l32; sums row r serves cy = r (top pair) and cy = r - 8 (bottom pair) */
+    const uint16_t *s8 = (const uint16_t *)s_s8;
+    uint32_t lb[33];
+    {
+        const uint16_t *colp = s8 + row0 * T2_SU + col0 + l32;
+#pragma unroll
+        for (int r = 0; r < 41; r++) {
+            const uint32_t p = (uint32_t)colp[r * T2_SU] | ((uint32_t)colp[r * T2_SU + 8] << 16);
+            if (r <= 32) lb[r] = __builtin_amdgcn_sad_u16(p, ctop, 0u);
+            if (r >= 8) lb[r - 8] = __builtin_amdgcn_sad_u16(p, cbot, lb[r - 8]);
+        }
+    }
+    uint32_t lbx0, lbx1 = 0xffffffffu; /* column cx = 32: lane l32 owns cy = l32, lane 0 also cy = 32 */
+    {
+        const uint16_t *colp = s8 + row0 * T2_SU + col0 + 32;
+        uint32_t p = (uint32_t)colp[l32 * T2_SU] | ((uint32_t)colp[l32 * T2_SU + 8] << 16);
+        uint32_t a = __builtin_amdgcn_sad_u16(p, ctop, 0u);
+        p = (uint32_t)colp[(l32 + 8) * T2_SU] | ((uint32_t)colp[(l32 + 8) * T2_SU + 8] << 16);
+        lbx0 = __builtin_amdgcn_sad_u16(p, cbot, a);
+        if (l32 == 0) {
+            p = (uint32_t)colp[32 * T2_SU] | ((uint32_t)colp[32 * T2_SU + 8] << 16);
+            a = __builtin_amdgcn_sad_u16(p, ctop, 0u);
+            p = (uint32_t)colp[40 * T2_SU] | ((uint32_t)colp[40 * T2_SU + 8] << 16);
+            lbx1 = __builtin_amdgcn_sad_u16(p, cbot, a);
+        }
+    }
+
+    /* ---- P4: starting points, survivors, evaluation ---- */
+    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
+    const uint32_t prev = B.mvsad_prev[mbidx];
+    const int pcx = (int)(int8_t)(prev & 255u) + 16, pcy = (int)(int8_t)((prev >> 8) & 255u) + 16;
+    /* third starting point: the candidate with the smallest lower bound */
+    uint32_t lmin = (lbx0 << 12) | (uint32_t)(l32 * 33 + 32);
+    lmin = min(lmin, lbx1 == 0xffffffffu ? 0xffffffffu : ((lbx1 << 12) | (uint32_t)(32 * 33 + 32)));
+#pragma unroll
+    for (int cy = 0; cy < 33; cy++) lmin = min(lmin, (lb[cy] << 12) | (uint32_t)(cy * 33 + l32));
+    const int ai = (int)(half_min32(lmin, lane) & 4095u);
+    const int acy = ai / 33, acx = ai - acy * 33;
+    const uint32_t sad_z = me2_coop_sad(s_win, col0, row0, lane, c0, c1, 16, 16);
+    const uint32_t sad_p = me2_coop_sad(s_win, col0, row0, lane, c0, c1, pcx, pcy);
+    const uint32_t sad_a = me2_coop_sad(s_win, col0, row0, lane, c0, c1, acx, acy);
+    uint32_t best = min(min((sad_z << 11) | rank[16 * 33 + 16], (sad_p << 11) | rank[pcy * 33 + pcx]), (sad_a << 11) | rank[ai]);
+    {
+        const uint32_t thr = min(min(sad_z, sad_p), sad_a);
+#pragma unroll
+        for (int cy = 0; cy < 33; cy++) {
+            if (lb[cy] <= thr) {
+                const uint32_t pos = atomicAdd(&s_cnt[hw], 1u);
+                if (pos < SEA_LIST) s_list[hw][pos] = (lb[cy] << 12) | (uint32_t)(cy * 33 + l32);
+            }
+        }
+        if (lbx0 <= thr) {
+            const uint32_t pos = atomicAdd(&s_cnt[hw], 1u);
+            if (pos < SEA_LIST) s_list[hw][pos] = (lbx0 << 12) | (uint32_t)(l32 * 33 + 32);
+        }
+        if (lbx1 <= thr) {
+            const uint32_t pos = atomicAdd(&s_cnt[hw], 1u);
+            if (pos < SEA_LIST) s_list[hw][pos] = (lbx1 << 12) | (uint32_t)(32 * 33 + 32);
+        }
+    }
+    __syncthreads();
+    const uint32_t cnt = s_cnt[hw];
+    const bool overflow = cnt > SEA_LIST;
+    const uint32_t cnt_eff = overflow ? 0u : cnt;
+    const uint32_t n = max(cnt_eff, (uint32_t)__shfl((int)cnt_eff, hbase ^ 32));
+    uint32_t bsad = best >> 11; /* threshold follows the SADs directly, the rank lookup stays off the critical path */
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t e = k < cnt_eff ? s_list[hw][k] : 0xffffffffu;
+        const int ci = (int)(e & 4095u);
+        const bool need = k < cnt_eff && (e >> 12) <= bsad && ci != ai && ci != 16 * 33 + 16 && ci != pcy * 33 + pcx;
+        if (__ballot(need) == 0ull) continue; /* neither macroblock of this wave needs the evaluation */
+        const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
+        const uint32_t sad = me2_coop_sad(s_win, col0, row0, lane, c0, c1, cx, cy);
+        bsad = min(bsad, sad);
+        best = min(best, (sad << 11) | rank[cy * 33 + cx]);
+    }
+    if (l32 == 0 && mb_valid) {
+        const uint32_t cand = B.me_cand[best & 2047u];
+        const int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
+        B.mvsad[mbidx] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+        B.me_flag[mbidx] = overflow ? 1 : 0;
+        if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(my * g.mbw + mx);
+        B.me_cnt[mbidx] = (uint8_t)min(cnt, 255u); /* survivors of the bound test (introspection) */
+    }
+}
+
+/* Exhaustive redo of the macroblocks k_me_tile flagged (bound not selective enough), one
+ * macroblock per block so that the few flagged ones (around occlusions; ~0.5 % on the synthetic
+ * clip) run side by side instead of dragging whole tiles along.  The four waves of a block split
+ * the 33 vertical displacements (9 each, the last wave's tail is masked); lane = horizontal
+ * displacement.  k_me_tile appended the macroblock indices to fix_list / fix_count. */
+#define FIX_BLOCKS 64
+#define FIX_WD 13 /* window row: 48 bytes + 4 spare, in dwords */
+#define FIX_NDY 9
+
+__global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_win[(48 + 4) * FIX_WD];
+    __shared__ uint32_t s_cur[16 * 4];
+    __shared__ uint32_t s_best[4];
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
+    int rstride, cstride, pw, ph;
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
+        const int mb = (int)B.fix_list[(size_t)item * g.nmb + i];
+        const int mx = mb % g.mbw, my = mb / g.mbw;
+        const int x0 = mx * 16, y0 = my * 16;
+        __syncthreads();
+        for (int k = tid; k < 52 * 12; k += 256) {
+            const int r = k / 12, d = k - r * 12;
+            const uint8_t *row = ref + (size_t)clampi(y0 - 16 + r, 0, g.ch - 1) * rstride;
+            const int xb = x0 - 16 + 4 * d;
+            s_win[r * FIX_WD + d] = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
+                                    ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) |
+                                    ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
+        }
+        if (tid < 52) s_win[tid * FIX_WD + 12] = 0;
+        if (tid < 64) {
+            const int r = tid >> 2, d = tid & 3;
+            const uint8_t *row = cur + (size_t)min(y0 + r, g.h - 1) * cstride;
+            const int xb = x0 + 4 * d;
+            s_cur[tid] = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
+                         ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+        }
+        __syncthreads();
+        uint32_t c[16][4];
+#pragma unroll
+        for (int y = 0; y < 16; y++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) c[y][j] = s_cur[y * 4 + j];
+        uint32_t acc[FIX_NDY];
+#pragma unroll
+        for (int k = 0; k < FIX_NDY; k++) acc[k] = 0;
+        const int dy0 = wave * FIX_NDY;          /* first dy index of this wave */
+        const int dxi = lane < 33 ? lane : 32;   /* lanes 33..63 repeat column 32 and are ignored */
+        const int dw = dxi >> 2;
+        const uint32_t sh = (uint32_t)(dxi & 3);
+#pragma unroll
+        for (int r = 0; r < FIX_NDY + 15; r++) {
+            const uint32_t *row = s_win + min(dy0 + r, 51) * FIX_WD + dw;
+            const uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3], d4 = row[4];
+            const uint32_t r0 = __builtin_amdgcn_alignbyte(d1, d0, sh), r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            const uint32_t r2 = __builtin_amdgcn_alignbyte(d3, d2, sh), r3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+#pragma unroll
+            for (int y = 0; y < 16; y++) {
+                const int k = r - y;
+                if (k >= 0 && k < FIX_NDY) {
+                    uint32_t a = acc[k];
+                    a = __builtin_amdgcn_sad_u8(r0, c[y][0], a);
+                    a = __builtin_amdgcn_sad_u8(r1, c[y][1], a);
+                    a = __builtin_amdgcn_sad_u8(r2, c[y][2], a);
+                    a = __builtin_amdgcn_sad_u8(r3, c[y][3], a);
+                    acc[k] = a;
+                }
+            }
+        }
+        uint32_t best = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < FIX_NDY; k++) {
+            const int dyi = dy0 + k;
+            if (dyi <= 32 && lane < 33) best = min(best, (acc[k] << 11) | B.me_rank[dyi * 33 + dxi]);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
+        if (lane == 0) s_best[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            best = min(min(s_best[0], s_best[1]), min(s_best[2], s_best[3]));
+            const uint32_t cand = B.me_cand[best & 2047u];
+            const int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
+            B.mvsad[(size_t)item * g.nmb + mb] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+        }
+    }
+}

@@ -21,10 +21,12 @@
  * closed GOPs are queued and advances them together, one kernel sequence per
  * frame index, so each launch covers G x (macroblocks per frame) work items.
  */
+#define _POSIX_C_SOURCE 200809L
 #include "../../include/x264.h"
 
 #include <math.h>
 #include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -60,6 +62,12 @@ struct x264_t {
     int nal_cap;
     int external_input; /* venc_set_input is active (resident mode) */
 };
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+}
 
 static const char *const k_presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast",
                                         "medium",    "slow",      "slower",   "veryslow", "placebo", NULL};
@@ -375,7 +383,10 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
     x264_nal_t *nals;
     int nn;
     x264_picture_t po;
+    const int trace = getenv("VENC_TRACE") != NULL; /* host-side phase times to stderr */
+    double t_launch = 0, t_asm = 0, t_sink = 0, t0 = now_ms(), ta;
     while (f < n_frames || h->n_out < h->n_in) {
+        ta = now_ms();
         /* keep the GPU queue full: register frames while output slots are free */
         while (f < n_frames && h->n_in - h->n_out < h->pool) {
             shim_frame *fr = &h->ring[h->n_in % h->pool];
@@ -389,15 +400,23 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
             if (launch_pending(h, 0) != 0) return -1;
         }
         if (f >= n_frames && launch_pending(h, 1) != 0) return -1;
+        t_launch += now_ms() - ta;
+        ta = now_ms();
         /* package the oldest unit while the GPU works on the next one, then hand it over in display order */
         if (assemble_next_unit(h) != 0) return -1;
+        t_asm += now_ms() - ta;
+        ta = now_ms();
         while (h->n_out < h->n_asm) {
             const int bytes = deliver(h, &nals, &nn, &po);
             if (bytes < 0) return -1;
             if (sink && sink(user, nals, nn, bytes, &po) != 0) return -1;
             delivered++;
         }
+        t_sink += now_ms() - ta;
     }
+    if (trace)
+        fprintf(stderr, "venc trace: %d frames, total %.3f ms = launch %.3f + package(wait+escape) %.3f + sink %.3f\n", delivered,
+                now_ms() - t0, t_launch, t_asm, t_sink);
     h->external_input = 0;
     return delivered;
 }
@@ -413,11 +432,17 @@ int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int 
     uint64_t hsh = t->fnv1a ? t->fnv1a : 1469598103934665603ull;
     const uint8_t *p = nals[0].p_payload;
     int i = 0;
-    for (; i + 8 <= payload_bytes; i += 8) {
-        uint64_t wd;
-        memcpy(&wd, p + i, 8);
-        hsh = (hsh ^ wd) * 1099511628211ull;
+    /* four independent multiply chains over 32-byte stripes, folded at the end of the frame */
+    uint64_t h0 = hsh, h1 = hsh ^ 0x9E3779B97F4A7C15ull, h2 = hsh ^ 0xC2B2AE3D27D4EB4Full, h3 = hsh ^ 0x165667B19E3779F9ull;
+    for (; i + 32 <= payload_bytes; i += 32) {
+        uint64_t w[4];
+        memcpy(w, p + i, 32);
+        h0 = (h0 ^ w[0]) * 1099511628211ull;
+        h1 = (h1 ^ w[1]) * 1099511628211ull;
+        h2 = (h2 ^ w[2]) * 1099511628211ull;
+        h3 = (h3 ^ w[3]) * 1099511628211ull;
     }
+    hsh = (((h0 * 31 + h1) * 31 + h2) * 31 + h3);
     for (; i < payload_bytes; i++) hsh = (hsh ^ p[i]) * 1099511628211ull;
     t->fnv1a = hsh;
     t->frames++;
