@@ -103,6 +103,9 @@ int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, const int *o
 int venc_mark(venc_ctx *c);
 int venc_wait(venc_ctx *c, int ticket);
 int venc_sync(venc_ctx *c);
+/* 1 (default): the entropy kernels of a step (k_cavlc, k_scan, k_pack) run on a second HIP
+ * stream beside the next step's motion/transform kernels; 0: one stream, no concurrency. */
+int venc_set_overlap(venc_ctx *c, int enable);
 
 /* Output of out slot `slot` (valid after the producing step completed). */
 int venc_get_frame(venc_ctx *c, int slot, venc_frame *out);

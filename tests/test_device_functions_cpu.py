@@ -17,6 +17,7 @@ def hc(venc):
     L.hc_fdct4.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_idct4.argtypes = [C.c_void_p, C.c_void_p]
     L.hc_cavlc_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    L.hc_cavlc_block_mem.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
     L.hc_ue_bits.argtypes = [C.c_uint, C.c_void_p]
     L.hc_se_bits.argtypes = [C.c_int, C.c_void_p]
     L.hc_table.argtypes = [C.c_int, C.c_void_p]
@@ -101,6 +102,10 @@ def test_cavlc_block_matches_oracle(hc, orc):
                         assert bits_h == bits_o and bits_h > 0
                         nb = (bits_h + 7) // 8
                         assert bytes(out_h[:nb]) == bytes(out_o[:nb]), (max_coef, nC, blk)
+                        # the data-driven variant the kernel uses (levels in memory, tables in one array)
+                        c_mem = c_dev.astype(np.int16)
+                        bits_m = hc.hc_cavlc_block_mem(c_mem.ctypes.data, first, max_coef, nC, out_h.ctypes.data, 128)
+                        assert bits_m == bits_o and bytes(out_h[:nb]) == bytes(out_o[:nb]), (max_coef, nC, blk)
                         cases += 1
     assert cases > 2000
 

@@ -242,3 +242,29 @@ def test_reference_block_sums_plane(venc):
     want = (s8[:H, :W] | (s8[:H, 8:W + 8] << 16)).astype(np.uint32)
     assert np.array_equal(p8[:H, :W], want)
     eng.close()
+
+
+def test_legacy_and_split_inter_kernels_agree(venc):
+    """k_inter_luma + k_inter_chroma (homogeneous waves) against the first k_inter."""
+    import os
+    w, h, n = 352, 288, 4
+    frames = [venc.synth_frame(w, h, t, 55) for t in range(n)]
+    outs = []
+    for mode in ("legacy", "split"):
+        os.environ["VENC_INTER"] = mode
+        try:
+            eng = venc.Engine(w, h, qp=24, n_slices=3, max_items=1, in_slots=2, out_slots=2)
+        finally:
+            os.environ.pop("VENC_INTER", None)
+        res = []
+        for t, (y, u, v) in enumerate(frames):
+            eng.upload(t % 2, y, u, v)
+            eng.encode_step([t % 2], [t % 2], t == 0, t & 15, [0])
+            eng.sync()
+            res.append((eng.debug(1), eng.debug(2)[:, :26], eng.debug(4), eng.debug(5), eng.debug(6), eng.get_slices(t % 2)))
+        eng.close()
+        outs.append(res)
+    for t in range(n):
+        for k in range(5):
+            assert np.array_equal(outs[0][t][k], outs[1][t][k]), "frame %d output %d" % (t, k)
+        assert outs[0][t][5] == outs[1][t][5]

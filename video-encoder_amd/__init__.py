@@ -143,6 +143,7 @@ def hip_lib():
         L.venc_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.venc_synth_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32]
         L.venc_profile.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.venc_set_overlap.argtypes = [C.c_void_p, C.c_int]
         L.venc_profile_name.restype = C.c_char_p
         L.venc_profile_name.argtypes = [C.c_int]
         L.venc_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -389,6 +390,10 @@ class X264Encoder:
     def profile(self, enable=True, capacity=8192):
         if hip_lib().venc_profile(self.L.x264_venc_engine(self.h), int(enable), capacity) != 0:
             raise VencError("venc_profile failed")
+
+    def set_overlap(self, enable):
+        if hip_lib().venc_set_overlap(self.L.x264_venc_engine(self.h), int(bool(enable))) != 0:
+            raise VencError("venc_set_overlap failed")
 
     def profile_read(self):
         H = hip_lib()

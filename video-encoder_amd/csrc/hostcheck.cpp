@@ -49,6 +49,28 @@ int hc_cavlc_block(const int *c, int first, int max_coef, int nC, unsigned char 
     for (int i = 0; i < nb; i++) out[i] = (unsigned char)(words[i >> 2] >> (24 - 8 * (i & 3)));
     return bits;
 }
+/* data-driven variant used by k_cavlc: levels in memory, tables concatenated as the kernel stages them */
+int hc_cavlc_block_mem(const short *c16, int first, int max_coef, int nC, unsigned char *out, int cap_bytes) {
+    static uint16_t tab[VENC_TAB_SIZE];
+    static int init = 0;
+    if (!init) {
+        memcpy(tab + VENC_TAB_TOKEN, venc_vlc_coeff_token, 272 * 2);
+        memcpy(tab + VENC_TAB_TOKEN_CDC, venc_vlc_coeff_token_cdc, 20 * 2);
+        memcpy(tab + VENC_TAB_TZ, venc_vlc_total_zeros, 240 * 2);
+        memcpy(tab + VENC_TAB_TZ_CDC, venc_vlc_total_zeros_cdc, 12 * 2);
+        memcpy(tab + VENC_TAB_RUN, venc_vlc_run_before, 112 * 2);
+        init = 1;
+    }
+    uint32_t words[32];
+    venc_bitsink b;
+    venc_bs_init(&b, words);
+    venc_cavlc_block_mem(&b, c16, venc_nzmask_mem(c16, first, max_coef), first, max_coef, nC, tab);
+    int bits = venc_bs_flush(&b);
+    int nb = (bits + 7) / 8;
+    if (nb > cap_bytes) return -1;
+    for (int i = 0; i < nb; i++) out[i] = (unsigned char)(words[i >> 2] >> (24 - 8 * (i & 3)));
+    return bits;
+}
 int hc_ue_bits(unsigned v, unsigned char *out) {
     uint32_t words[4];
     venc_bitsink b;

@@ -259,6 +259,90 @@ VENC_DEV int venc_cavlc_block(venc_bitsink *b, const int c[16], int first, int m
     return total;
 }
 
+/* ---------------------------------------------------------------- CAVLC block, data-driven
+ * Same syntax as venc_cavlc_block, but the levels sit in (lane-private) memory and every loop
+ * walks the set bits of the non-zero mask instead of all 16 positions: the work is proportional
+ * to the number of coefficients (1-4 in a typical P block).  tab = the five VLC tables back to
+ * back (see VENC_TAB_* offsets), staged in LDS by the kernel.
+ *   c   : 16 levels, scan order; the block occupies c[first .. first+max_coef-1]
+ *   nz  : bit k set iff c[first+k] != 0 */
+#define VENC_TAB_TOKEN 0
+#define VENC_TAB_TOKEN_CDC 272
+#define VENC_TAB_TZ 292
+#define VENC_TAB_TZ_CDC 532
+#define VENC_TAB_RUN 544
+#define VENC_TAB_SIZE 656
+
+VENC_DEV uint32_t venc_nzmask_mem(const int16_t *c, int first, int max_coef) {
+    uint32_t nz = 0;
+    for (int k = 0; k < max_coef; k++) nz |= (uint32_t)(c[first + k] != 0) << k;
+    return nz;
+}
+
+VENC_DEV int venc_cavlc_block_mem(venc_bitsink *b, const int16_t *c, uint32_t nz, int first, int max_coef, int nC,
+                                  const uint16_t *tab) {
+    const int total = venc_popc(nz);
+    int t1 = 0;
+    uint32_t m = nz, signs = 0;
+    while (t1 < 3 && m) {
+        const int i = venc_ilog2(m);
+        const int v = c[first + i];
+        if (v != 1 && v != -1) break;
+        signs = (signs << 1) | (uint32_t)(v < 0);
+        t1++;
+        m ^= 1u << i;
+    }
+    const uint32_t tok = nC < 0 ? tab[VENC_TAB_TOKEN_CDC + 4 * total + t1]
+                                : tab[VENC_TAB_TOKEN + (nC < 2 ? 0 : nC < 4 ? 68 : nC < 8 ? 136 : 204) + 4 * total + t1];
+    venc_bs_put(b, tok & 0xff, (int)(tok >> 8));
+    if (total == 0) return 0;
+    venc_bs_put(b, signs, t1);
+    int sl = (total > 10 && t1 < 3) ? 1 : 0;
+    int first_level = 1;
+    while (m) {
+        const int i = venc_ilog2(m);
+        m ^= 1u << i;
+        const int lv = c[first + i];
+        const int alv = lv < 0 ? -lv : lv;
+        int code = 2 * alv - 2 + (lv < 0);
+        if (first_level && t1 < 3) code -= 2;
+        first_level = 0;
+        if (sl == 0) {
+            if (code < 14)
+                venc_bs_put(b, 1, code + 1);
+            else if (code < 30)
+                venc_bs_put(b, 16u | (uint32_t)(code - 14), 19);
+            else
+                venc_bs_put(b, 4096u | (uint32_t)(code - 30), 28);
+        } else {
+            if (code < (15 << sl))
+                venc_bs_put(b, (1u << sl) | (uint32_t)(code & ((1 << sl) - 1)), (code >> sl) + 1 + sl);
+            else
+                venc_bs_put(b, 4096u | (uint32_t)(code - (15 << sl)), 28);
+        }
+        if (sl == 0) sl = 1;
+        if (alv > (3 << (sl - 1)) && sl < 6) sl++;
+    }
+    const int total_zeros = venc_ilog2(nz) + 1 - total;
+    if (total < max_coef) {
+        const uint32_t tz = (max_coef == 4) ? tab[VENC_TAB_TZ_CDC + 4 * (total - 1) + total_zeros]
+                                            : tab[VENC_TAB_TZ + 16 * (total - 1) + total_zeros];
+        venc_bs_put(b, tz & 0xff, (int)(tz >> 8));
+    }
+    int zeros_left = total_zeros;
+    uint32_t rest = nz;
+    while (zeros_left > 0) {
+        const int i = venc_ilog2(rest);
+        rest ^= 1u << i;
+        if (!rest) break;
+        const int run = i - venc_ilog2(rest) - 1;
+        const uint32_t rb = tab[VENC_TAB_RUN + 16 * ((zeros_left > 7 ? 7 : zeros_left) - 1) + run];
+        venc_bs_put(b, rb & 0xff, (int)(rb >> 8));
+        zeros_left -= run;
+    }
+    return total;
+}
+
 /* nC from the neighbouring blocks' TotalCoeff (9.2.1) */
 VENC_DEV int venc_nc(int availA, int nA, int availB, int nB) {
     if (availA && availB) return (nA + nB + 1) >> 1;

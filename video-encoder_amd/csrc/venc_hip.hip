@@ -19,6 +19,7 @@
 #include "venc_kernels.hip"
 #include "venc_me.hip"
 #include "venc_me2.hip"
+#include "venc_inter2.hip"
 #include "venc_synth.h"
 
 static thread_local char g_err[512] = "";
@@ -55,7 +56,9 @@ struct venc_ctx {
     uint8_t *d_row_slice;
     uint16_t *d_rank, *d_cand;
     int intra_waves;
+    int max_slice_mbs;
     int steps_done;
+    int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
     int me_mode;  /* 0 tile (default): successive elimination, sums built in-kernel; 1 plane: sums from k_refsum;
                      2 dense: exhaustive search.  Env VENC_ME=tile|plane|dense (VENC_ME_DENSE=1 = dense). */
     /* optional per-kernel HIP-event timing (venc_profile) */
@@ -65,8 +68,8 @@ struct venc_ctx {
     int prof_n, prof_cap;
 };
 
-enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_COUNT };
-static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix"};
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_COUNT };
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma"};
 
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
     if (!c->prof_on || c->prof_n >= c->prof_cap) return;
@@ -227,6 +230,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         rows[g.n_slices] = r;
     }
     c->intra_waves = maxrows < INTRA_MAX_WAVES ? maxrows : INTRA_MAX_WAVES;
+    c->max_slice_mbs = maxrows * g.mbw;
     OPEN_OK(hipMalloc(&c->d_slice_rows, sizeof(int) * (g.n_slices + 1)));
     OPEN_OK(hipMemcpy(c->d_slice_rows, rows, sizeof(int) * (g.n_slices + 1), hipMemcpyHostToDevice));
     OPEN_OK(hipMalloc(&c->d_row_slice, (size_t)g.mbh));
@@ -281,6 +285,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (m && !strcmp(m, "dense")) c->me_mode = 2;
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
+    c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
     OPEN_OK(hipMalloc(&b.fix_count, G * 4));
@@ -441,9 +446,18 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
         }
-        prof_begin(c, KID_INTER, s1);
-        hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
-        prof_end(c, s1);
+        if (c->inter_legacy) {
+            prof_begin(c, KID_INTER, s1);
+            hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
+            prof_end(c, s1);
+        } else {
+            prof_begin(c, KID_INTER, s1);
+            hipLaunchKernelGGL(k_inter_luma, dim3((g.nmb + 15) / 16, 1, n_items), dim3(256), 0, s1, g, b, S);
+            prof_end(c, s1);
+            prof_begin(c, KID_INTER_C, s1);
+            hipLaunchKernelGGL(k_inter_chroma, dim3((g.nmb + 31) / 32, 1, n_items), dim3(256), 0, s1, g, b, S);
+            prof_end(c, s1);
+        }
     }
     if (c->me_mode == 1) { /* block sums of the frame just reconstructed = reference of the next P step */
         prof_begin(c, KID_REFSUM, s1);
@@ -466,7 +480,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, s2, g, b, S, c->d_slice);
     prof_end(c, s2);
     prof_begin(c, KID_PACK, s2);
-    hipLaunchKernelGGL(k_pack, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S,
+    hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, g.n_slices, n_items), dim3(256), 0, s2, g, b, S,
                        (const venc_slice_out *)c->d_slice);
     prof_end(c, s2);
     HIP_OK(hipGetLastError());
@@ -492,6 +506,16 @@ extern "C" int venc_wait(venc_ctx *c, int ticket) {
 extern "C" int venc_sync(venc_ctx *c) {
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
+    return 0;
+}
+
+/* 1 (default): the entropy chain of a step runs on a second stream beside the next step's main
+ * chain; 0: every kernel on one stream (isolated per-kernel timings for the roofline report) */
+extern "C" int venc_set_overlap(venc_ctx *c, int enable) {
+    HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream2));
+    c->overlap = enable ? 1 : 0;
+    c->side_used[0] = c->side_used[1] = 0;
     return 0;
 }
 

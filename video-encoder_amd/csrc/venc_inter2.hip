@@ -1,0 +1,212 @@
+/*
+ * venc_inter2.hip -- P_L0_16x16 transform / quantisation / reconstruction with every lane busy
+ * (SURVEY.md section 8a rows a4.2, a4.3, a4.5).
+ *
+ * The first version (k_inter in venc_kernels.hip) gave one half-wave to each macroblock: 16 luma
+ * lanes, 8 chroma lanes, 8 idle, and the luma and chroma prediction paths ran one after the
+ * other under divergence -- ~415 wave instructions per macroblock.  Here luma and chroma are
+ * separate launches with homogeneous waves:
+ *   k_inter_luma    16 lanes per macroblock, 4 macroblocks per wave   (lane = luma4x4BlkIdx)
+ *   k_inter_chroma   8 lanes per macroblock, 8 macroblocks per wave   (lane = plane*4 + block)
+ * Quantiser constants are wave-uniform (SGPRs), no per-lane selects.  k_inter_luma writes the
+ * luma half of coded_block_pattern, k_inter_chroma (next on the stream) ORs in the chroma half.
+ */
+
+template <bool DC_SEP>
+DEVFN void blk_quant_recon(const int w[16], const venc_qparams &q, int f, int d0, const int pred[16], int lv[16], int rec[16],
+                           int &nnz) {
+    int d[16];
+    nnz = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = venc_zigzag_ct(i);
+        const int cls = venc_pos_class(r);
+        int l = venc_quant_mag(w[r], q.mf[cls], f, q.qbits);
+        if (DC_SEP && i == 0) l = 0;
+        lv[i] = l;
+        nnz += (l != 0);
+        d[r] = (l * q.v[cls]) << q.per;
+    }
+    if (DC_SEP) d[0] = d0;
+    int rr[16];
+    venc_idct4(d, rr);
+#pragma unroll
+    for (int i = 0; i < 16; i++) rec[i] = venc_clip_u8(pred[i] + rr[i]);
+}
+
+DEVFN void store_levels(int16_t *dst16, const int lv[16]) {
+    uint32_t p[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) p[i] = ((uint32_t)lv[2 * i] & 0xffffu) | ((uint32_t)lv[2 * i + 1] << 16);
+    uint4 *dst = (uint4 *)dst16;
+    dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
+    dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+}
+DEVFN void store_rec4x4(uint8_t *rec, int rstride, int px, int py, const int r[16]) {
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        const uint32_t v = (uint32_t)r[4 * y] | ((uint32_t)r[4 * y + 1] << 8) | ((uint32_t)r[4 * y + 2] << 16) | ((uint32_t)r[4 * y + 3] << 24);
+        *(uint32_t *)(rec + (size_t)(py + y) * rstride + px) = v;
+    }
+}
+DEVFN void unpack4(uint32_t v, int *o) {
+    o[0] = (int)(v & 255u), o[1] = (int)((v >> 8) & 255u), o[2] = (int)((v >> 16) & 255u), o[3] = (int)(v >> 24);
+}
+/* current 4x4 block: aligned dword rows inside the display area, clamped bytes on its edges */
+DEVFN void load_cur4x4(const uint8_t *cur, int cstride, int pw, int ph, int px, int py, bool aligned, int c[16]) {
+    if (aligned && px + 4 <= pw && py + 4 <= ph) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) unpack4(*(const uint32_t *)(cur + (size_t)(py + y) * cstride + px), c + 4 * y);
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_inter_luma(venc_geom g, venc_bufs B, venc_step S) {
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int lane = tid & 63, blk = lane & 15, gbase = lane & 48;
+    const int mb_raw = blockIdx.x * 16 + (tid >> 4);
+    const bool valid = mb_raw < g.nmb;
+    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
+    const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
+    const int dx = (int)(int8_t)(mvs & 255u), dy = (int)(int8_t)((mvs >> 8) & 255u);
+
+    int cstride, pw, ph, rstride, wstride;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
+
+    int c[16], p[16];
+    load_cur4x4(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, c);
+    const int x0 = px + dx, y0 = py + dy;
+    if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
+        const uint32_t sh = (uint32_t)(x0 & 3);
+        const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint32_t *r32 = (const uint32_t *)(rp + (size_t)y * rstride);
+            unpack4(__builtin_amdgcn_alignbyte(r32[1], r32[0], sh), p + 4 * y);
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++)
+                p[4 * y + x] = ref[(size_t)clampi(y0 + y, 0, g.ch - 1) * rstride + clampi(x0 + x, 0, g.cw - 1)];
+    }
+    int res[16], w[16], lv[16], rr[16], nnz;
+#pragma unroll
+    for (int i = 0; i < 16; i++) res[i] = c[i] - p[i];
+    venc_fdct4(res, w);
+    blk_quant_recon<false>(w, g.ql, g.ql.f_inter, 0, p, lv, rr, nnz);
+
+    int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
+    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+    const unsigned long long bal = __ballot(nnz > 0);
+    if (valid) {
+        if (nnz) store_levels(lv_mb + blk * 16, lv);
+        info->nnz[blk_y(blk) * 4 + blk_x(blk)] = (uint8_t)nnz;
+        store_rec4x4(rec, wstride, px, py, rr);
+        if (blk == 0) {
+            const uint32_t h = (uint32_t)(bal >> gbase) & 0xffffu;
+            int cbpl = 0;
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                if ((h >> (4 * qd)) & 15u) cbpl |= 1 << qd;
+            info->cbp = (uint8_t)cbpl; /* k_inter_chroma adds the chroma bits */
+            info->flags = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_inter_chroma(venc_geom g, venc_bufs B, venc_step S) {
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int lane = tid & 63, k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
+    const int mb_raw = blockIdx.x * 32 + (tid >> 3);
+    const bool valid = mb_raw < g.nmb;
+    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
+    const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
+    const int dx = (int)(int8_t)(mvs & 255u), dy = (int)(int8_t)((mvs >> 8) & 255u);
+
+    int cstride, pw, ph, rstride, wstride;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, plane, rstride);
+    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
+    const int rw = g.cw >> 1, rh = g.ch >> 1;
+
+    int c[16], p[16];
+    load_cur4x4(cur, cstride, pw, ph, px, py, (g.w & 7) == 0, c);
+    /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
+    const int x0 = px + (dx >> 1), y0 = py + (dy >> 1);
+    const int xf = (dx & 1) * 4, yf = (dy & 1) * 4;
+    int smp[5][5];
+    if (x0 >= 0 && x0 + 8 <= rw && y0 >= 0 && y0 + 5 <= rh) {
+        const uint32_t sh = (uint32_t)(x0 & 3);
+        const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
+#pragma unroll
+        for (int y = 0; y < 5; y++) {
+            const uint32_t *r32 = (const uint32_t *)(rp + (size_t)y * rstride);
+            const uint32_t d0 = r32[0], d1 = r32[1];
+            unpack4(__builtin_amdgcn_alignbyte(d1, d0, sh), smp[y]);
+            smp[y][4] = (int)(__builtin_amdgcn_alignbyte(0u, d1, sh) & 255u);
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) smp[y][x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
+    }
+    const int wa = (8 - xf) * (8 - yf), wb = xf * (8 - yf), wc = (8 - xf) * yf, wd = xf * yf;
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            p[4 * y + x] = (wa * smp[y][x] + wb * smp[y][x + 1] + wc * smp[y + 1][x] + wd * smp[y + 1][x + 1] + 32) >> 6;
+
+    int res[16], w[16], lv[16], rr[16], nnz;
+#pragma unroll
+    for (int i = 0; i < 16; i++) res[i] = c[i] - p[i];
+    venc_fdct4(res, w);
+    /* 2x2 DC transform over the four lanes of the plane */
+    int yc = 0;
+#pragma unroll
+    for (int qi = 0; qi < 4; qi++) {
+        const int v = __shfl(w[0], qbase | qi);
+        yc += (__popc(k & qi) & 1) ? -v : v;
+    }
+    const int dclv = venc_quant_chroma_dc(yc, &g.qc, 0);
+    int fc = 0;
+#pragma unroll
+    for (int qi = 0; qi < 4; qi++) {
+        const int v = __shfl(dclv, qbase | qi);
+        fc += (__popc(k & qi) & 1) ? -v : v;
+    }
+    blk_quant_recon<true>(w, g.qc, g.qc.f_inter, venc_dequant_chroma_dc(fc, &g.qc), p, lv, rr, nnz);
+
+    int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
+    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+    const int dc0 = __shfl(dclv, qbase | 0), dc1 = __shfl(dclv, qbase | 1), dc2 = __shfl(dclv, qbase | 2), dc3 = __shfl(dclv, qbase | 3);
+    const unsigned long long bal_ac = __ballot(nnz > 0), bal_dc = __ballot(dclv != 0);
+    if (valid) {
+        const int pk = (plane - 1) * 4 + k;
+        if (nnz) store_levels(lv_mb + (19 + pk) * 16, lv);
+        info->nnz[16 + pk] = (uint8_t)nnz;
+        store_rec4x4(rec, wstride, px, py, rr);
+        if (k == 0) {
+            uint4 *dst = (uint4 *)(lv_mb + (16 + plane) * 16);
+            dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16), ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
+        }
+        if ((lane & 7) == 0) {
+            const uint32_t hac = (uint32_t)(bal_ac >> gbase) & 0xffu, hdc = (uint32_t)(bal_dc >> gbase) & 0xffu;
+            const int cbpc = hac ? 2 : hdc ? 1 : 0;
+            info->cbp = (uint8_t)((info->cbp & 15) | (cbpc << 4));
+        }
+    }
+}

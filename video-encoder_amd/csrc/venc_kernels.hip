@@ -52,6 +52,55 @@ DEVFN int blk_x(int b) { return (b & 1) | ((b >> 1) & 2); }
 DEVFN int blk_y(int b) { return ((b >> 1) & 1) | ((b >> 2) & 2); }
 DEVFN int blk_of(int x, int y) { return (x & 1) | ((y & 1) << 1) | ((x >> 1) << 2) | ((y >> 1) << 3); }
 
+/* ---- half-wave (32-lane) reductions on the DPP network: 4 row_shr steps inside each row of 16
+ * lanes, one row_bcast:15 into rows 1 and 3, then the totals are read from lanes 31 and 63.
+ * About 8 VALU/SALU instructions and no LDS traffic (ds_bpermute butterflies cost ~5 LDS round trips). */
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_BCAST15 0x142
+template <int CTRL, int ROWMASK>
+DEVFN uint32_t dpp_fetch(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROWMASK, 0xf, false);
+}
+DEVFN uint32_t half_sum32(uint32_t v, int lane) {
+    v += dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0u);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return lane < 32 ? lo : hi;
+}
+DEVFN uint32_t half_min32(uint32_t v, int lane) {
+    v = min(v, dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0xffffffffu));
+    v = min(v, dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0xffffffffu));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    return lane < 32 ? lo : hi;
+}
+
+/* inclusive prefix sum inside each 32-lane half of a wave */
+DEVFN uint32_t half_scan_incl32(uint32_t v) {
+    v += dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0u);
+    return v;
+}
+/* inclusive prefix sum over the 64 lanes of a wave (row scans + row_bcast:15 / row_bcast:31) */
+#define DPP_ROW_BCAST31 0x143
+DEVFN uint32_t wave_scan_incl(uint32_t v) {
+    v += dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0u);
+    v += dpp_fetch<DPP_ROW_BCAST31, 0xc>(v, 0u);
+    return v;
+}
+
 /* ================================================================== k_me
  * One block = 8 horizontally adjacent macroblocks of one MB row; one half-wave
  * (32 lanes) per macroblock.  Lane l of a half-wave owns displacement column
@@ -578,14 +627,81 @@ DEVFN void load_levels(const int16_t *src, int c[16]) {
     }
 }
 
+/* slice_header(), 7.3.3 -- written by the lane that codes the first macroblock of a slice */
+DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int item) {
+    venc_bs_ue(bs, (uint32_t)mb);
+    venc_bs_ue(bs, S.is_idr ? 7u : 5u);
+    venc_bs_ue(bs, 0);
+    venc_bs_put(bs, (uint32_t)S.frame_num & 15u, 4);
+    if (S.is_idr) {
+        venc_bs_ue(bs, (uint32_t)S.idr_id[item]);
+        venc_bs_put(bs, 0, 2); /* no_output_of_prior_pics, long_term_reference */
+    } else {
+        venc_bs_put(bs, 0, 3); /* override, list modification, adaptive marking */
+    }
+    venc_bs_se(bs, 0); /* slice_qp_delta */
+    venc_bs_ue(bs, 1); /* disable_deblocking_filter_idc */
+}
+
+/* mb_skip_run, mb_type, mvd (median prediction 8.4.1.3.1), coded_block_pattern, mb_qp_delta of a P_L0_16x16 macroblock */
+DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t *mvs, int mb, int mx, int my, bool aL, bool aT,
+                            int cbp) {
+    (void)my;
+    const uint32_t me = mvs[mb];
+    const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+    bool aA = aL, aB = aT, aC = aT && (mx + 1 < g.mbw);
+    const bool aD = aT && mx > 0;
+    int ax = 0, ay = 0, bxv = 0, byv = 0, cx = 0, cy = 0;
+    if (aA) {
+        uint32_t m = mvs[mb - 1];
+        ax = (int)(int8_t)(m & 255u), ay = (int)(int8_t)((m >> 8) & 255u);
+    }
+    if (aB) {
+        uint32_t m = mvs[mb - g.mbw];
+        bxv = (int)(int8_t)(m & 255u), byv = (int)(int8_t)((m >> 8) & 255u);
+    }
+    if (aC) {
+        uint32_t m = mvs[mb - g.mbw + 1];
+        cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
+    } else if (aD) {
+        uint32_t m = mvs[mb - g.mbw - 1];
+        aC = true;
+        cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
+    }
+    int pxv, pyv;
+    if (!aB && !aC && aA)
+        pxv = ax, pyv = ay;
+    else if ((int)aA + (int)aB + (int)aC == 1)
+        pxv = aA ? ax : aB ? bxv : cx, pyv = aA ? ay : aB ? byv : cy;
+    else
+        pxv = venc_median3(ax, bxv, cx), pyv = venc_median3(ay, byv, cy);
+    venc_bs_ue(bs, 0); /* mb_skip_run */
+    venc_bs_ue(bs, 0); /* mb_type P_L0_16x16 */
+    venc_bs_se(bs, 4 * (dx - pxv));
+    venc_bs_se(bs, 4 * (dy - pyv));
+    venc_bs_ue(bs, venc_cbp_inter_code[cbp]);
+    if (cbp) venc_bs_se(bs, 0);
+}
+
 __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ uint32_t s_priv[CAVLC_MBS * 32 * VENC_LANE_WORDS];
     __shared__ uint32_t s_mb[CAVLC_MBS][VENC_MB_WORDS + 2];
+    __shared__ uint32_t s_lv[CAVLC_MBS * 32 * 9]; /* per lane: 16 levels (8 dwords) + 1 dword of padding against bank conflicts */
+    __shared__ uint16_t s_tab[VENC_TAB_SIZE];
     const int item = blockIdx.z, tid = threadIdx.x;
     const int team = tid >> 5, lane = tid & 63, l32 = lane & 31, base = lane & 32;
-    const int mb_raw = blockIdx.x * CAVLC_MBS + team;
-    const bool valid = mb_raw < g.nmb;
-    const int mb = valid ? mb_raw : g.nmb - 1;
+    for (int i = tid; i < VENC_TAB_SIZE; i += 256)
+        s_tab[i] = i < VENC_TAB_TOKEN_CDC ? venc_vlc_coeff_token[i]
+                 : i < VENC_TAB_TZ      ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
+                 : i < VENC_TAB_TZ_CDC  ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
+                 : i < VENC_TAB_RUN     ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
+                                        : venc_vlc_run_before[i - VENC_TAB_RUN];
+    __syncthreads();
+    const uint32_t count = (uint32_t)g.nmb;
+    for (uint32_t tbase = blockIdx.x * CAVLC_MBS; tbase < count; tbase += gridDim.x * CAVLC_MBS) {
+    const uint32_t ti = tbase + (uint32_t)team;
+    const bool valid = ti < count;
+    const int mb = valid ? (int)ti : 0;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int srow = B.slice_first_row[B.row_slice[my]];
     const bool aL = mx > 0, aT = my > srow;
@@ -654,86 +770,41 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     venc_bitsink bs;
     venc_bs_init(&bs, s_priv + (team * 32 + l32) * VENC_LANE_WORDS);
     if (coded) {
-        int c[16];
         /* AC / luma blocks with nnz = 0 were not written by the transform kernels */
         bool empty = false;
         if (l32 >= 2 && l32 < 18)
             empty = info->nnz[blk_y(l32 - 2) * 4 + blk_x(l32 - 2)] == 0;
         else if (l32 >= 20 && l32 < 28)
             empty = info->nnz[16 + (l32 - 20)] == 0;
-        if (empty) {
+        uint32_t *strip = s_lv + (team * 32 + l32) * 9;
+        uint32_t nz = 0;
+        if (!empty) {
+            const int16_t *src = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16;
+            const uint4 a = ((const uint4 *)src)[0], bq = ((const uint4 *)src)[1];
+            const uint32_t wds[8] = {a.x, a.y, a.z, a.w, bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-            for (int i = 0; i < 16; i++) c[i] = 0;
-        } else {
-            load_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16, c);
+            for (int i = 0; i < 8; i++) {
+                strip[i] = wds[i];
+                nz |= (uint32_t)((wds[i] & 0xffffu) != 0u) << (2 * i);
+                nz |= (uint32_t)((wds[i] >> 16) != 0u) << (2 * i + 1);
+            }
+            nz = (nz >> first) & ((1u << maxc) - 1u);
         }
-        venc_cavlc_block(&bs, c, first, maxc, nC);
+        venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, first, maxc, nC, s_tab);
     }
     if (l32 == 0 && valid) {
-        if (mx == 0 && my == srow) { /* slice_header(), 7.3.3 */
-            venc_bs_ue(&bs, (uint32_t)mb);
-            venc_bs_ue(&bs, S.is_idr ? 7u : 5u);
-            venc_bs_ue(&bs, 0);
-            venc_bs_put(&bs, (uint32_t)S.frame_num & 15u, 4);
-            if (S.is_idr) {
-                venc_bs_ue(&bs, (uint32_t)S.idr_id[item]);
-                venc_bs_put(&bs, 0, 2); /* no_output_of_prior_pics, long_term_reference */
-            } else {
-                venc_bs_put(&bs, 0, 3); /* override, list modification, adaptive marking */
-            }
-            venc_bs_se(&bs, 0); /* slice_qp_delta */
-            venc_bs_ue(&bs, 1); /* disable_deblocking_filter_idc */
-        }
+        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
         if (i16) {
             venc_bs_ue(&bs, (uint32_t)(1 + 2 + 4 * cbpc + 12 * (cbpl != 0)));
             venc_bs_ue(&bs, 0);
             venc_bs_se(&bs, 0);
         } else {
-            const uint32_t *mvs = B.mvsad + (size_t)item * g.nmb;
-            const uint32_t me = mvs[mb];
-            const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
-            bool aA = aL, aB = aT, aC = aT && (mx + 1 < g.mbw);
-            const bool aD = aT && mx > 0;
-            int ax = 0, ay = 0, bxv = 0, byv = 0, cx = 0, cy = 0;
-            if (aA) {
-                uint32_t m = mvs[mb - 1];
-                ax = (int)(int8_t)(m & 255u), ay = (int)(int8_t)((m >> 8) & 255u);
-            }
-            if (aB) {
-                uint32_t m = mvs[mb - g.mbw];
-                bxv = (int)(int8_t)(m & 255u), byv = (int)(int8_t)((m >> 8) & 255u);
-            }
-            if (aC) {
-                uint32_t m = mvs[mb - g.mbw + 1];
-                cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
-            } else if (aD) {
-                uint32_t m = mvs[mb - g.mbw - 1];
-                aC = true;
-                cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
-            }
-            int pxv, pyv;
-            if (!aB && !aC && aA)
-                pxv = ax, pyv = ay;
-            else if ((int)aA + (int)aB + (int)aC == 1)
-                pxv = aA ? ax : aB ? bxv : cx, pyv = aA ? ay : aB ? byv : cy;
-            else
-                pxv = venc_median3(ax, bxv, cx), pyv = venc_median3(ay, byv, cy);
-            venc_bs_ue(&bs, 0); /* mb_skip_run */
-            venc_bs_ue(&bs, 0); /* mb_type P_L0_16x16 */
-            venc_bs_se(&bs, 4 * (dx - pxv));
-            venc_bs_se(&bs, 4 * (dy - pyv));
-            venc_bs_ue(&bs, venc_cbp_inter_code[cbp]);
-            if (cbp) venc_bs_se(&bs, 0);
+            emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp);
         }
     }
     const int nbits = venc_bs_flush(&bs);
     /* inclusive prefix over the 32 lanes of the team */
-    int incl = nbits;
-#pragma unroll
-    for (int d = 1; d < 32; d <<= 1) {
-        int t = __shfl_up(incl, d, 32);
-        if (l32 >= d) incl += t;
-    }
+    int incl = (int)half_scan_incl32((uint32_t)nbits);
     int total = __shfl(incl, base | 31);
     if (total > VENC_MB_WORDS * 32) total = VENC_MB_WORDS * 32; /* cannot happen for QP >= 12; keeps LDS in bounds */
     const int off = incl - nbits;
@@ -758,60 +829,44 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         for (int j = l32; j < nw; j += 32) dst[j] = s_mb[team][j];
         if (l32 == 0) B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)total;
     }
+    __syncthreads(); /* LDS strips are reused by the next macroblock group */
+    }
 }
 
 /* ================================================================== k_scan
  * One block per item: per-slice exclusive scan of macroblock bit counts and the
  * slice table (byte offsets inside the frame's output buffer). */
 __global__ __launch_bounds__(1024) void k_scan(venc_geom g, venc_bufs B, venc_step S, venc_slice_out *slice_dev) {
-    __shared__ uint32_t s_wsum[16];
-    __shared__ uint32_t s_running;
+    __shared__ uint32_t s_bits[VENC_MAX_SLICES];
     const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
     uint32_t *offp = B.mboff + (size_t)item * g.nmb;
-    uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
-    venc_slice_out *host_tab = (venc_slice_out *)(slot + sizeof(venc_out_header));
-    uint32_t byte_off = 0;
-    for (int s = 0; s < g.n_slices; s++) {
+    /* one wave per slice (round-robin): 64 macroblocks per DPP scan, running total carried in a scalar */
+    for (int s = wv; s < g.n_slices; s += 16) {
         const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
-        if (tid == 0) s_running = 0;
-        __syncthreads();
-        for (int b0 = first; b0 < last; b0 += 1024) {
-            const int i = b0 + tid;
+        uint32_t running = 0;
+        for (int b0 = first; b0 < last; b0 += 64) {
+            const int i = b0 + lane;
             const uint32_t v = i < last ? nb[i] : 0u;
-            uint32_t incl = v;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                uint32_t t = (uint32_t)__shfl_up((int)incl, d, 64);
-                if (lane >= d) incl += t;
-            }
-            if (lane == 63) s_wsum[wv] = incl;
-            __syncthreads();
-            uint32_t wbase = 0, tot = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                uint32_t x = s_wsum[k];
-                if (k < wv) wbase += x;
-                tot += x;
-            }
-            const uint32_t run = s_running;
-            if (i < last) offp[i] = run + wbase + incl - v;
-            __syncthreads();
-            if (tid == 0) s_running = run + tot;
-            __syncthreads();
+            const uint32_t incl = wave_scan_incl(v);
+            if (i < last) offp[i] = running + incl - v;
+            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        const uint32_t nbits = s_running;
-        const uint32_t nbytes = (nbits + 1 + 7) >> 3;
-        if (tid == 0) {
-            venc_slice_out so = {byte_off, nbytes, nbits, 0};
+        if (lane == 0) s_bits[s] = running;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
+        venc_slice_out *host_tab = (venc_slice_out *)(slot + sizeof(venc_out_header));
+        uint32_t byte_off = 0;
+        for (int s = 0; s < g.n_slices; s++) {
+            const uint32_t nbits = s_bits[s], nbytes = (nbits + 1 + 7) >> 3;
+            const venc_slice_out so = {byte_off, nbytes, nbits, 0};
             slice_dev[(size_t)item * g.n_slices + s] = so;
             host_tab[s] = so;
+            byte_off += (nbytes + 3u) & ~3u;
         }
-        byte_off += (nbytes + 3u) & ~3u;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        venc_out_header h = {byte_off, (uint32_t)g.n_slices, byte_off > B.out_cap ? 1u : 0u, 0};
+        const venc_out_header h = {byte_off, (uint32_t)g.n_slices, byte_off > B.out_cap ? 1u : 0u, 0};
         *(venc_out_header *)slot = h;
     }
 }
@@ -827,30 +882,49 @@ DEVFN uint32_t fetch_bits(const uint32_t *wds, int pos, int n) { /* 1 <= n <= 32
     return (uint32_t)((two >> (64 - shb - n)) & (n == 32 ? 0xffffffffull : ((1ull << n) - 1ull)));
 }
 
+#define PACK_MBS 256
+/* One block per run of up to 256 consecutive macroblocks of a slice; consecutive lanes build
+ * consecutive output words (coalesced stores towards the pinned host buffer).  The bit offsets of
+ * the run sit in LDS; a word finds its first macroblock by binary search there. */
 __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_step S, const venc_slice_out *slice_dev) {
-    const int item = blockIdx.z;
-    const int mb = blockIdx.x * 256 + threadIdx.x;
-    if (mb >= g.nmb) return;
-    const int my = mb / g.mbw;
-    const int s = B.row_slice[my];
+    __shared__ uint32_t s_off[PACK_MBS], s_nb[PACK_MBS];
+    const int item = blockIdx.z, s = blockIdx.y, tid = threadIdx.x;
+    const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
+    const int m0 = first + blockIdx.x * PACK_MBS;
+    if (m0 >= last) return;
+    const int n_here = min(PACK_MBS, last - m0);
     const venc_slice_out so = slice_dev[(size_t)item * g.n_slices + s];
-    const int last_mb = B.slice_first_row[s + 1] * g.mbw;
     const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
     const uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     const uint32_t *bits = B.mbbits + (size_t)item * g.nmb * VENC_MB_WORDS;
     uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
     uint32_t *out = (uint32_t *)(slot + B.out_data_off + so.byte_off);
-
+    if (tid < n_here) {
+        s_off[tid] = offp[m0 + tid];
+        s_nb[tid] = nb[m0 + tid];
+    }
+    __syncthreads();
     const uint32_t T = so.nbits;
-    const uint32_t off = offp[mb], n = nb[mb];
-    uint32_t end = off + n;
-    if (mb == last_mb - 1) end = so.nbytes * 8u; /* owner of the trailing bits */
-    for (uint32_t w = (off + 31u) >> 5; 32u * w < end; w++) {
+    const uint32_t begin = s_off[0];
+    const uint32_t end = (m0 + n_here == last) ? so.nbytes * 8u : s_off[n_here - 1] + s_nb[n_here - 1];
+    for (uint32_t w = ((begin + 31u) >> 5) + (uint32_t)tid; 32u * w < end; w += 256u) {
         if (so.byte_off + 4u * (w + 1u) > B.out_cap) break;
         uint32_t pos = 32u * w, val = 0;
-        int got = 0, m = mb;
-        while (got < 32 && m < last_mb) {
-            const uint32_t mo = offp[m], mn = nb[m];
+        int lo = 0, hi = n_here - 1;
+        while (lo < hi) { /* last macroblock of the run whose offset is <= pos */
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_off[mid] <= pos)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        int got = 0, m = lo;
+        while (got < 32 && m0 + m < last) {
+            uint32_t mo, mn;
+            if (m < n_here)
+                mo = s_off[m], mn = s_nb[m];
+            else
+                mo = offp[m0 + m], mn = nb[m0 + m]; /* the word runs on into the next block's macroblocks */
             const uint32_t local = pos - mo;
             if (local >= mn) {
                 m++;
@@ -858,7 +932,7 @@ __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_ste
             }
             uint32_t take = mn - local;
             if (take > (uint32_t)(32 - got)) take = (uint32_t)(32 - got);
-            const uint32_t v = fetch_bits(bits + (size_t)m * VENC_MB_WORDS, (int)local, (int)take);
+            const uint32_t v = fetch_bits(bits + (size_t)(m0 + m) * VENC_MB_WORDS, (int)local, (int)take);
             val = take == 32 ? v : ((val << take) | v);
             got += (int)take;
             pos += take;

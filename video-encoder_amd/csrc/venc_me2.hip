@@ -29,34 +29,6 @@
 DEVFN uint2 pk4_add(uint2 a, uint2 b) { return make_uint2(a.x + b.x, a.y + b.y); }
 DEVFN uint2 pk4_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y); }
 
-/* ---- half-wave (32-lane) reductions on the DPP network: 4 row_shr steps inside each row of 16
- * lanes, one row_bcast:15 into rows 1 and 3, then the totals are read from lanes 31 and 63.
- * About 8 VALU/SALU instructions and no LDS traffic (ds_bpermute butterflies cost ~5 LDS round trips). */
-#define DPP_ROW_SHR(n) (0x110 + (n))
-#define DPP_ROW_BCAST15 0x142
-template <int CTRL, int ROWMASK>
-DEVFN uint32_t dpp_fetch(uint32_t v, uint32_t fill) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, CTRL, ROWMASK, 0xf, false);
-}
-DEVFN uint32_t half_sum32(uint32_t v, int lane) {
-    v += dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0u);
-    v += dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0u);
-    v += dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0u);
-    v += dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0u);
-    v += dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0u);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    return lane < 32 ? lo : hi;
-}
-DEVFN uint32_t half_min32(uint32_t v, int lane) {
-    v = min(v, dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0xffffffffu));
-    v = min(v, dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0xffffffffu));
-    v = min(v, dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0xffffffffu));
-    v = min(v, dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0xffffffffu));
-    v = min(v, dpp_fetch<DPP_ROW_BCAST15, 0xa>(v, 0xffffffffu));
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)v, 31), hi = (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-    return lane < 32 ? lo : hi;
-}
-
 /* SAD of one macroblock at window position (col0 + cx, row0 + cy), 8 pixels per lane of a half-wave */
 DEVFN uint32_t me2_coop_sad(const uint32_t *s_win, int col0, int row0, int lane, uint32_t c0, uint32_t c1, int cx, int cy) {
     const int l32 = lane & 31;
