@@ -494,6 +494,21 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
  * five integers per macroblock through a small LDS ring. */
 #define INTRA_MAX_WAVES 16
 
+/* four rows of a current 4x4 block as packed dwords (aligned loads inside the display area, clamped bytes on its edges) */
+DEVFN void load_cur_rows(const uint8_t *cur, int cstride, int pw, int ph, int px, int py, bool aligned, uint32_t q[4]) {
+    if (aligned && px + 4 <= pw && py + 4 <= ph) {
+#pragma unroll
+        for (int y = 0; y < 4; y++) q[y] = *(const uint32_t *)(cur + (size_t)(py + y) * cstride + px);
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint8_t *row = cur + (size_t)min(py + y, ph - 1) * cstride;
+            q[y] = (uint32_t)row[min(px, pw - 1)] | ((uint32_t)row[min(px + 1, pw - 1)] << 8) |
+                   ((uint32_t)row[min(px + 2, pw - 1)] << 16) | ((uint32_t)row[min(px + 3, pw - 1)] << 24);
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ int s_bot[INTRA_MAX_WAVES][4][5];
     const int item = blockIdx.z, s = blockIdx.x, tid = threadIdx.x;
@@ -514,9 +529,17 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
         const int my = cb + wv;
         const int steps = g.mbw + nr - 1;
         int leftY = 0, leftC0 = 0, leftC1 = 0; /* per lane: sums relevant to this lane's plane */
+        /* the current block's pixels are fetched one macroblock ahead so that the load latency
+         * hides behind the previous macroblock's arithmetic instead of sitting on the dependency chain */
+        const bool cur_al = luma ? ((g.w & 3) == 0) : ((g.w & 7) == 0);
+        const int pyl = (luma ? my * 16 : my * 8) + by;
+        uint32_t cq[4] = {0, 0, 0, 0};
+        if (wv < nr) load_cur_rows(cur, cstride, pw, ph, bx, pyl, cur_al, cq);
         for (int step = 0; step < steps; step++) {
             const int mx = step - wv;
             if (wv < nr && mx >= 0 && mx < g.mbw) {
+                uint32_t nq[4] = {0, 0, 0, 0};
+                if (mx + 1 < g.mbw) load_cur_rows(cur, cstride, pw, ph, (luma ? (mx + 1) * 16 : (mx + 1) * 8) + bx, pyl, cur_al, nq);
                 const int mb = my * g.mbw + mx;
                 const bool aL = mx > 0, aT = my > r0;
                 /* top sums: [0] luma, [1],[2] Cb halves, [3],[4] Cr halves */
@@ -552,9 +575,11 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                 for (int y = 0; y < 4; y++)
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
-                        c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
+                        c[4 * y + x] = (int)((cq[y] >> (8 * x)) & 255u);
                         p[4 * y + x] = pred;
                     }
+#pragma unroll
+                for (int y = 0; y < 4; y++) cq[y] = nq[y];
                 mb_lane_out o;
                 mb_code<true, true>(lane, c, p, g, o);
 
@@ -686,7 +711,6 @@ DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t
 __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ uint32_t s_priv[CAVLC_MBS * 32 * VENC_LANE_WORDS];
     __shared__ uint32_t s_mb[CAVLC_MBS][VENC_MB_WORDS + 2];
-    __shared__ uint32_t s_lv[CAVLC_MBS * 32 * 9]; /* per lane: 16 levels (8 dwords) + 1 dword of padding against bank conflicts */
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
     const int item = blockIdx.z, tid = threadIdx.x;
     const int team = tid >> 5, lane = tid & 63, l32 = lane & 31, base = lane & 32;
@@ -776,7 +800,8 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
             empty = info->nnz[blk_y(l32 - 2) * 4 + blk_x(l32 - 2)] == 0;
         else if (l32 >= 20 && l32 < 28)
             empty = info->nnz[16 + (l32 - 20)] == 0;
-        uint32_t *strip = s_lv + (team * 32 + l32) * 9;
+        /* level strips (8 dwords + 1 of padding per lane) live in the team's still unused bit-string buffer */
+        uint32_t *strip = &s_mb[team][0] + l32 * 9;
         uint32_t nz = 0;
         if (!empty) {
             const int16_t *src = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16;

@@ -87,13 +87,21 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     }
     __syncthreads();
     /* ---- P1: horizontal 8-sums, four columns per item ---- */
-    for (int i = tid; i < T2_WR * T2_HG; i += 512) {
-        const int r = i / T2_HG, q = i - r * T2_HG;
-        const uint32_t *p = s_win + r * T2_WD + q;
-        const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
-        const unsigned long long a = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d1 << 32) | d0, 0u, 0ull);
-        const unsigned long long b = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)d2 << 32) | d1, 0u, 0ull);
-        s_h8[i] = pk4_add(make_uint2((uint32_t)a, (uint32_t)(a >> 32)), make_uint2((uint32_t)b, (uint32_t)(b >> 32)));
+    {   /* thread = (row, run of 5 column groups): 6 sliding-sum instructions give 5 groups of 8-sums */
+        const int r = tid >> 3, q0 = (tid & 7) * 5;
+        const uint32_t *p = s_win + r * T2_WD + q0;
+        uint32_t dwd[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) dwd[k] = p[k]; /* q0 + 6 <= 41: inside the padded row */
+        uint2 h4[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const unsigned long long a = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)dwd[k + 1] << 32) | dwd[k], 0u, 0ull);
+            h4[k] = make_uint2((uint32_t)a, (uint32_t)(a >> 32));
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            if (q0 + k < T2_HG) s_h8[r * T2_HG + q0 + k] = pk4_add(h4[k], h4[k + 1]);
     }
     __syncthreads();
     /* ---- P2: vertical 8-sums: 8 segments of up to 8 rows x 39 column groups ---- */
