@@ -268,3 +268,36 @@ def test_legacy_and_split_inter_kernels_agree(venc):
         for k in range(5):
             assert np.array_equal(outs[0][t][k], outs[1][t][k]), "frame %d output %d" % (t, k)
         assert outs[0][t][5] == outs[1][t][5]
+
+
+def test_lane_per_macroblock_cavlc_equals_half_wave_cavlc(venc):
+    """k_cavlc_p (P pictures, one lane per macroblock) against k_cavlc (one lane per block)."""
+    import os
+    w, h, n = 352, 288, 5
+    rng = np.random.default_rng(8)
+    clips = {
+        "synth": [venc.synth_frame(w, h, t, 77) for t in range(n)],
+        # heavy residual: independent noise frames -> many large levels, escapes, long blocks
+        "noise": [tuple(rng.integers(0, 256, s).astype(np.uint8) for s in ((h, w), (h // 2, w // 2), (h // 2, w // 2)))
+                  for _ in range(n)],
+    }
+    for name, frames in clips.items():
+        for qp in (12, 30):
+            outs = []
+            for mode in ("legacy", "lane"):
+                os.environ["VENC_CAVLC"] = mode
+                try:
+                    eng = venc.Engine(w, h, qp=qp, n_slices=3, max_items=1, in_slots=2, out_slots=2)
+                finally:
+                    os.environ.pop("VENC_CAVLC", None)
+                res = []
+                for t, (y, u, v) in enumerate(frames):
+                    eng.upload(t % 2, y, u, v)
+                    eng.encode_step([t % 2], [t % 2], t == 0, t & 15, [0])
+                    eng.sync()
+                    res.append((eng.debug(3), eng.get_slices(t % 2)))
+                eng.close()
+                outs.append(res)
+            for t in range(n):
+                assert np.array_equal(outs[0][t][0], outs[1][t][0]), "%s qp%d frame %d: macroblock bit counts" % (name, qp, t)
+                assert outs[0][t][1] == outs[1][t][1], "%s qp%d frame %d: slice bytes" % (name, qp, t)

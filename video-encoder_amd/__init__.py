@@ -23,7 +23,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_HIP = os.path.join(CSRC, "libvenc_hip.so")
+LIB_HIP = os.path.join(CSRC, os.environ.get("VENC_HIP_LIB", "libvenc_hip.so"))  # VENC_HIP_LIB: diagnostic builds
 LIB_X264 = os.path.join(CSRC, "libx264_venc.so")
 LIB_HOSTCHECK = os.path.join(CSRC, "libvenc_hostcheck.so")
 
@@ -259,7 +259,8 @@ class Engine:
         shapes = {0: ((self.nmb,), np.uint32), 1: ((self.nmb, 27, 16), np.int16), 2: ((self.nmb, 32), np.uint8),
                   3: ((self.nmb,), np.uint32), 4: ((ch, cw), np.uint8), 5: ((ch // 2, cw // 2), np.uint8),
                   6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32),
-                  8: ((ch + 25, (cw + 32) & ~15), np.uint32), 9: ((self.nmb,), np.uint8), 10: ((self.nmb,), np.uint8)}
+                  8: ((ch + 25, (cw + 32) & ~15), np.uint32), 9: ((self.nmb,), np.uint8), 10: ((self.nmb,), np.uint8),
+                  11: ((8,), np.uint64)}
         shape, dt = shapes[what]
         a = np.empty(shape, dt)
         self._ok(self.L.venc_debug_read(self.h, what, item, a.ctypes.data, a.nbytes), "venc_debug_read")

@@ -1,0 +1,115 @@
+/*
+ * venc_cavlc_p.hip -- entropy coding of P pictures with ONE LANE PER MACROBLOCK
+ * (SURVEY.md section 8a row a4.4).
+ *
+ * A P macroblock of typical content carries a handful of levels in one or two 4x4 blocks
+ * (3-4 levels per coded macroblock on the synthetic clip).  k_cavlc gives every macroblock a
+ * half-wave with one lane per block: 28 lanes for ~2 busy ones, plus prefix sums and an LDS
+ * concatenation.  Here a lane walks its own macroblock in syntax order -- header, the coded luma
+ * blocks, chroma DC, chroma AC -- and appends to its own bit string in HBM (the macroblock's
+ * region of mbbits) through a 64-bit accumulator; no cross-lane step at all.  The wave's time is
+ * the heaviest of its 64 macroblocks, which for P pictures is a few blocks.  I pictures (26
+ * dense blocks in every macroblock) stay on k_cavlc.
+ */
+
+__global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_lv[256 * 9]; /* per lane: the 16 levels of the block being coded (+1 dword against bank conflicts) */
+    __shared__ uint16_t s_tab[VENC_TAB_SIZE];
+    const int item = blockIdx.z, tid = threadIdx.x;
+    uint16_t tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = tid + 256 * k;
+        tv[k] = i >= VENC_TAB_SIZE      ? (uint16_t)0
+              : i < VENC_TAB_TOKEN_CDC  ? venc_vlc_coeff_token[i]
+              : i < VENC_TAB_TZ         ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
+              : i < VENC_TAB_TZ_CDC     ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
+              : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
+                                        : venc_vlc_run_before[i - VENC_TAB_RUN];
+    }
+    const int mb_raw = blockIdx.x * 256 + tid;
+    const bool valid = mb_raw < g.nmb;
+    const int mb = valid ? mb_raw : 0;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int srow = slice_first_row_of(g, my);
+    const bool aL = mx > 0, aT = my > srow;
+    const venc_mbinfo *infos = B.mbinfo + (size_t)item * g.nmb;
+    const uint4 *ip = (const uint4 *)(infos + mb);
+    const uint4 *lp = (const uint4 *)(infos + (aL ? mb - 1 : mb));
+    const uint4 *tp = (const uint4 *)(infos + (aT ? mb - g.mbw : mb));
+    const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
+    __syncthreads();
+    if (!valid) return;
+
+    const int cbp = (int)(o1.z & 255u), cbpl = cbp & 15, cbpc = cbp >> 4;
+    uint32_t *strip = s_lv + tid * 9;
+    const int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
+    venc_bitsink bs;
+    venc_bs_init(&bs, B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS);
+    if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
+    emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp);
+
+    /* residual, syntax order: luma blocks of the coded 8x8s, chroma DC, chroma AC */
+    for (int slot = 0; slot < 27; slot++) {
+        if (slot == 16) continue; /* Intra16x16 DC: not in P macroblocks */
+        bool coded;
+        int first = 0, maxc = 16, nC = 0, own_idx = 0;
+        bool has_nnz_entry = true;
+        if (slot < 16) {
+            coded = (cbpl >> (slot >> 2)) & 1;
+            own_idx = blk_y(slot) * 4 + blk_x(slot);
+        } else if (slot < 19) {
+            coded = cbpc > 0;
+            maxc = 4;
+            nC = -1;
+            has_nnz_entry = false;
+        } else {
+            coded = cbpc == 2;
+            first = 1, maxc = 15;
+            own_idx = 16 + (slot - 19);
+        }
+        if (!coded) continue;
+        if (nC == 0) {
+            int ia, ib;
+            bool inA, inB;
+            if (slot < 16) {
+                const int bx = blk_x(slot), by = blk_y(slot);
+                inA = bx > 0, inB = by > 0;
+                ia = inA ? by * 4 + bx - 1 : by * 4 + 3;
+                ib = inB ? (by - 1) * 4 + bx : 12 + bx;
+            } else {
+                const int kk = (slot - 19) & 3, nb = 16 + 4 * ((slot - 19) >> 2);
+                const int bx = kk & 1, by = kk >> 1;
+                inA = bx > 0, inB = by > 0;
+                ia = inA ? nb + 2 * by : nb + 2 * by + 1;
+                ib = inB ? nb + bx : nb + 2 + bx;
+            }
+            const int nA = inA ? info_byte(o0, o1, ia) : info_byte(l0, l1, ia);
+            const int nB = inB ? info_byte(o0, o1, ib) : info_byte(t0, t1, ib);
+            nC = venc_nc(inA || aL, nA, inB || aT, nB);
+        }
+        uint32_t nz = 0;
+        if (!(has_nnz_entry && info_byte(o0, o1, own_idx) == 0)) { /* empty blocks were never written */
+            const uint4 a = ((const uint4 *)(lv_mb + slot * 16))[0];
+            strip[0] = a.x, strip[1] = a.y, strip[2] = a.z, strip[3] = a.w;
+            uint32_t wds[8] = {a.x, a.y, a.z, a.w, 0u, 0u, 0u, 0u};
+            if (maxc != 4) { /* chroma DC records hold 4 levels: one 16-byte load is enough */
+                const uint4 bq = ((const uint4 *)(lv_mb + slot * 16))[1];
+                strip[4] = bq.x, strip[5] = bq.y, strip[6] = bq.z, strip[7] = bq.w;
+                wds[4] = bq.x, wds[5] = bq.y, wds[6] = bq.z, wds[7] = bq.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                nz |= (uint32_t)((wds[i] & 0xffffu) != 0u) << (2 * i);
+                nz |= (uint32_t)((wds[i] >> 16) != 0u) << (2 * i + 1);
+            }
+            nz = (nz >> first) & ((1u << maxc) - 1u);
+        }
+        venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, first, maxc, nC, s_tab);
+    }
+    const int nbits = venc_bs_flush(&bs);
+    B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)nbits;
+}

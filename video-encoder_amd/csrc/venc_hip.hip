@@ -20,6 +20,7 @@
 #include "venc_me.hip"
 #include "venc_me2.hip"
 #include "venc_inter2.hip"
+#include "venc_cavlc_p.hip"
 #include "venc_synth.h"
 
 static thread_local char g_err[512] = "";
@@ -58,6 +59,7 @@ struct venc_ctx {
     int intra_waves;
     int max_slice_mbs;
     int steps_done;
+    int cavlc_legacy; /* VENC_CAVLC=legacy: half-wave-per-macroblock k_cavlc for P pictures too */
     int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
     int me_mode;  /* 0 tile (default): successive elimination, sums built in-kernel; 1 plane: sums from k_refsum;
                      2 dense: exhaustive search.  Env VENC_ME=tile|plane|dense (VENC_ME_DENSE=1 = dense). */
@@ -130,6 +132,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
+    (void)hipFree(c->b.stamps);
     (void)hipFree(c->b.fix_count);
     (void)hipFree(c->b.fix_list);
     (void)hipFree(c->d_slice);
@@ -194,6 +197,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     fill_qparams(&g.ql, cfg->qp);
     fill_qparams(&g.qc, cfg->qp < 30 ? cfg->qp : h_qpc_hi[cfg->qp - 30]);
     c->cfg.n_slices = g.n_slices;
+    g.slice_base = g.mbh / g.n_slices;
+    g.slice_rem = g.mbh % g.n_slices;
 
 #define OPEN_OK(call)               \
     do {                            \
@@ -239,7 +244,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
 
     /* ME tie-break order: all 33x33 displacements sorted by (|dx|+|dy|, dy, dx) */
     {
-        uint16_t rank[VENC_ME_CANDS], cand[VENC_ME_CANDS];
+        uint16_t rank[VENC_ME_CANDS + 1], cand[VENC_ME_CANDS]; /* rank padded to whole dwords (kernels stage it as 545 dwords) */
+        rank[VENC_ME_CANDS] = 0;
         int r = 0;
         for (int l1 = 0; l1 <= 2 * VENC_ME_RANGE; l1++)
             for (int dy = -VENC_ME_RANGE; dy <= VENC_ME_RANGE; dy++)
@@ -285,12 +291,15 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (m && !strcmp(m, "dense")) c->me_mode = 2;
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
+    c->cavlc_legacy = getenv("VENC_CAVLC") && !strcmp(getenv("VENC_CAVLC"), "legacy");
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
     OPEN_OK(hipMalloc(&b.fix_count, G * 4));
     OPEN_OK(hipMemset(b.fix_count, 0, G * 4));
     OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
+    OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMalloc(&b.me_cnt, G * nmb));
     OPEN_OK(hipMemset(b.me_cnt, 0, G * nmb));
     OPEN_OK(hipMalloc(&c->d_slice, G * g.n_slices * sizeof(venc_slice_out)));
@@ -470,7 +479,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         HIP_OK(hipStreamWaitEvent(s2, c->ev_main[p], 0));
     }
     prof_begin(c, KID_CAVLC, s2);
-    hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
+    if (is_idr || c->cavlc_legacy)
+        hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
+    else
+        hipLaunchKernelGGL(k_cavlc_p, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S);
     prof_end(c, s2);
     if (c->overlap) {
         HIP_OK(hipEventRecord(c->ev_side[p], s2));
@@ -563,6 +575,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         case 6: src = rec + (size_t)g.cw * g.ch * 5 / 4, n = (size_t)g.cw * g.ch / 4; break;
         case 7: src = c->b.mboff + item * nmb, n = nmb * 4; break;
         case 9: src = c->b.me_cnt + item * nmb, n = nmb; break;
+        case 11: src = c->b.stamps, n = 8 * sizeof(unsigned long long); break;
         case 10: src = c->b.me_flag + item * nmb, n = nmb; break;
         case 8: src = c->b.refsum + item * c->b.refsum_item, n = c->b.refsum_item * 4; break;
         default: SET_ERR("venc_debug_read: unknown selector %d", what); return -1;

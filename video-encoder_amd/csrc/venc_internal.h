@@ -54,6 +54,7 @@ typedef struct {
     int cw, ch;      /* coded */
     int mbw, mbh, nmb;
     int n_slices;
+    int slice_base, slice_rem; /* bands: the first slice_rem slices have slice_base+1 MB rows, the rest slice_base */
     int qp;
     venc_qparams ql, qc;
 } venc_geom;
@@ -91,6 +92,7 @@ typedef struct {
     uint8_t *me_flag;           /* [G][nmb] 1 = k_me_tile left this macroblock to k_me_fix */
     uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zeroed before k_me_tile) */
     uint32_t *fix_list;         /* [G][nmb] their indices */
+    unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
     uint8_t *out_base;          /* device view of the pinned output pool */
     size_t out_slot_bytes;

@@ -46,6 +46,11 @@ DEVFN uint8_t *rec_plane(const venc_bufs &B, const venc_geom &g, int parity, int
     return base + ysz + (plane == 2 ? (ysz >> 2) : 0);
 }
 DEVFN int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+/* first MB row of the slice that contains MB row my (bands are uniform: no table lookup, no memory round trip) */
+DEVFN int slice_first_row_of(const venc_geom &g, int my) {
+    const int big = g.slice_rem * (g.slice_base + 1);
+    return my < big ? (my / (g.slice_base + 1)) * (g.slice_base + 1) : big + ((my - big) / g.slice_base) * g.slice_base;
+}
 
 /* luma4x4BlkIdx <-> (x,y) in 4x4 units */
 DEVFN int blk_x(int b) { return (b & 1) | ((b >> 1) & 2); }
@@ -642,6 +647,12 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
  * macroblock's bit string in LDS and streamed out to HBM. */
 #define CAVLC_MBS 8
 
+/* byte idx (0..23) of a 32-byte macroblock record held in two uint4 */
+DEVFN int info_byte(const uint4 &a, const uint4 &b, int idx) {
+    const uint32_t w = idx < 4 ? a.x : idx < 8 ? a.y : idx < 12 ? a.z : idx < 16 ? a.w : idx < 20 ? b.x : b.y;
+    return (int)((w >> (8 * (idx & 3))) & 255u);
+}
+
 DEVFN void load_levels(const int16_t *src, int c[16]) {
     const uint4 a = ((const uint4 *)src)[0], b = ((const uint4 *)src)[1];
     const uint32_t wds[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -714,35 +725,49 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
     const int item = blockIdx.z, tid = threadIdx.x;
     const int team = tid >> 5, lane = tid & 63, l32 = lane & 31, base = lane & 32;
-    for (int i = tid; i < VENC_TAB_SIZE; i += 256)
-        s_tab[i] = i < VENC_TAB_TOKEN_CDC ? venc_vlc_coeff_token[i]
-                 : i < VENC_TAB_TZ      ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
-                 : i < VENC_TAB_TZ_CDC  ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
-                 : i < VENC_TAB_RUN     ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
+    /* VLC tables: global loads first, LDS writes after the macroblock records below are in flight */
+    uint16_t tv[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int i = tid + 256 * k;
+        tv[k] = i >= VENC_TAB_SIZE      ? (uint16_t)0
+              : i < VENC_TAB_TOKEN_CDC  ? venc_vlc_coeff_token[i]
+              : i < VENC_TAB_TZ         ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
+              : i < VENC_TAB_TZ_CDC     ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
+              : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                         : venc_vlc_run_before[i - VENC_TAB_RUN];
-    __syncthreads();
-    const uint32_t count = (uint32_t)g.nmb;
-    for (uint32_t tbase = blockIdx.x * CAVLC_MBS; tbase < count; tbase += gridDim.x * CAVLC_MBS) {
-    const uint32_t ti = tbase + (uint32_t)team;
-    const bool valid = ti < count;
-    const int mb = valid ? (int)ti : 0;
+    }
+    const int mb_raw = blockIdx.x * CAVLC_MBS + team;
+    const bool valid = mb_raw < g.nmb;
+    const int mb = valid ? mb_raw : 0;
     const int mx = mb % g.mbw, my = mb / g.mbw;
-    const int srow = B.slice_first_row[B.row_slice[my]];
+    const int srow = slice_first_row_of(g, my);
     const bool aL = mx > 0, aT = my > srow;
 
+    /* the macroblock's own 32-byte record and its left / top neighbours' (clamped), fetched whole
+     * and unconditionally: one memory round trip instead of a chain of dependent byte loads */
     const venc_mbinfo *infos = B.mbinfo + (size_t)item * g.nmb;
-    const venc_mbinfo *info = infos + mb;
-    const int cbp = info->cbp, cbpl = cbp & 15, cbpc = cbp >> 4;
-    const bool i16 = info->flags & 1;
+    const uint4 *ip = (const uint4 *)(infos + mb);
+    const uint4 *lp = (const uint4 *)(infos + (aL ? mb - 1 : mb));
+    const uint4 *tp = (const uint4 *)(infos + (aT ? mb - g.mbw : mb));
+    const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
+    __syncthreads();
+    const int cbp = (int)(o1.z & 255u), cbpl = cbp & 15, cbpc = cbp >> 4;
+    const bool i16 = (o1.z >> 8) & 1u;
 
     /* role decode */
     int slot = 0, first = 0, maxc = 16, nC = 0;
     bool coded = false;
+    int own_idx = 0; /* index of this lane's block in nnz[] */
     if (l32 == 1) {
         slot = 16;
         coded = i16;
     } else if (l32 >= 2 && l32 < 18) {
         slot = l32 - 2;
+        own_idx = blk_y(slot) * 4 + blk_x(slot);
         if (i16) {
             first = 1, maxc = 15;
             coded = cbpl != 0;
@@ -755,51 +780,37 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         coded = cbpc > 0;
     } else if (l32 >= 20 && l32 < 28) {
         slot = 19 + (l32 - 20);
+        own_idx = 16 + (l32 - 20);
         first = 1, maxc = 15;
         coded = cbpc == 2;
     }
     if (!valid) coded = false;
     /* nC from neighbouring TotalCoeff (9.2.1) */
     if (coded && nC == 0) {
+        int ia, ib;      /* nnz indices of the left / top neighbour block */
+        bool inA, inB;   /* neighbour block lies inside this macroblock */
         if (l32 < 18) {
             const int b = l32 == 1 ? 0 : l32 - 2;
             const int bx = blk_x(b), by = blk_y(b);
-            int nA = 0, nB = 0;
-            bool avA, avB;
-            if (bx > 0)
-                avA = true, nA = info->nnz[by * 4 + bx - 1];
-            else if ((avA = aL))
-                nA = infos[mb - 1].nnz[by * 4 + 3];
-            if (by > 0)
-                avB = true, nB = info->nnz[(by - 1) * 4 + bx];
-            else if ((avB = aT))
-                nB = infos[mb - g.mbw].nnz[12 + bx];
-            nC = venc_nc(avA, nA, avB, nB);
+            inA = bx > 0, inB = by > 0;
+            ia = inA ? by * 4 + bx - 1 : by * 4 + 3;
+            ib = inB ? (by - 1) * 4 + bx : 12 + bx;
         } else {
             const int kk = (l32 - 20) & 3, nb = 16 + 4 * ((l32 - 20) >> 2);
             const int bx = kk & 1, by = kk >> 1;
-            int nA = 0, nB = 0;
-            bool avA, avB;
-            if (bx > 0)
-                avA = true, nA = info->nnz[nb + 2 * by];
-            else if ((avA = aL))
-                nA = infos[mb - 1].nnz[nb + 2 * by + 1];
-            if (by > 0)
-                avB = true, nB = info->nnz[nb + bx];
-            else if ((avB = aT))
-                nB = infos[mb - g.mbw].nnz[nb + 2 + bx];
-            nC = venc_nc(avA, nA, avB, nB);
+            inA = bx > 0, inB = by > 0;
+            ia = inA ? nb + 2 * by : nb + 2 * by + 1;
+            ib = inB ? nb + bx : nb + 2 + bx;
         }
+        const int nA = inA ? info_byte(o0, o1, ia) : info_byte(l0, l1, ia);
+        const int nB = inB ? info_byte(o0, o1, ib) : info_byte(t0, t1, ib);
+        nC = venc_nc(inA || aL, nA, inB || aT, nB);
     }
     venc_bitsink bs;
     venc_bs_init(&bs, s_priv + (team * 32 + l32) * VENC_LANE_WORDS);
     if (coded) {
         /* AC / luma blocks with nnz = 0 were not written by the transform kernels */
-        bool empty = false;
-        if (l32 >= 2 && l32 < 18)
-            empty = info->nnz[blk_y(l32 - 2) * 4 + blk_x(l32 - 2)] == 0;
-        else if (l32 >= 20 && l32 < 28)
-            empty = info->nnz[16 + (l32 - 20)] == 0;
+        const bool empty = ((l32 >= 2 && l32 < 18) || (l32 >= 20 && l32 < 28)) && info_byte(o0, o1, own_idx) == 0;
         /* level strips (8 dwords + 1 of padding per lane) live in the team's still unused bit-string buffer */
         uint32_t *strip = &s_mb[team][0] + l32 * 9;
         uint32_t nz = 0;
@@ -854,8 +865,6 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         for (int j = l32; j < nw; j += 32) dst[j] = s_mb[team][j];
         if (l32 == 0) B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)total;
     }
-    __syncthreads(); /* LDS strips are reused by the next macroblock group */
-    }
 }
 
 /* ================================================================== k_scan
@@ -870,12 +879,20 @@ __global__ __launch_bounds__(1024) void k_scan(venc_geom g, venc_bufs B, venc_st
     for (int s = wv; s < g.n_slices; s += 16) {
         const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
         uint32_t running = 0;
-        for (int b0 = first; b0 < last; b0 += 64) {
-            const int i = b0 + lane;
-            const uint32_t v = i < last ? nb[i] : 0u;
-            const uint32_t incl = wave_scan_incl(v);
-            if (i < last) offp[i] = running + incl - v;
-            running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        for (int c0 = first; c0 < last; c0 += 64 * 16) { /* 16 loads in flight per lane, then 16 register scans */
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int i = c0 + 64 * k + lane;
+                v[k] = i < last ? nb[i] : 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int i = c0 + 64 * k + lane;
+                const uint32_t incl = wave_scan_incl(v[k]);
+                if (i < last) offp[i] = running + incl - v[k];
+                running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
         }
         if (lane == 0) s_bits[s] = running;
     }

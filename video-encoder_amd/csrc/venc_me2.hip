@@ -24,7 +24,23 @@
 #define T2_WD 42                 /* window row stride in dwords: 160 pixels + 8 bytes of zero padding */
 #define T2_HG 39                 /* groups of 4 columns with horizontal sums: columns 0..155 (0..152 used) */
 #define T2_SR (T2_MBY * 16 + 25) /* rows of block sums: 57 */
-#define T2_SU (T2_HG * 4)        /* sums row stride in u16: 156 */
+#define T2_SU (T2_HG * 4)        /* sums row stride in positions: 156 */
+#define T2_VR (T2_MBY * 16 + 17) /* rows of vertical pairs (cy + row0 <= 48): 49 */
+
+/* Diagnostic build only (-DVENC_ME_STAMPS, tools/me_stamps.py): per-phase wave-cycle sums of
+ * k_me_tile into B.stamps; the shipped library contains no stamp. */
+#ifdef VENC_ME_STAMPS
+#define ME_STAMP(i)                                                                         \
+    do {                                                                                    \
+        const unsigned long long t_ = clock64();                                            \
+        if ((threadIdx.x & 63) == 0) atomicAdd(&B.stamps[i], t_ - t_prev_);                 \
+        t_prev_ = t_;                                                                       \
+    } while (0)
+#define ME_STAMP_INIT unsigned long long t_prev_ = clock64()
+#else
+#define ME_STAMP(i) do { } while (0)
+#define ME_STAMP_INIT do { } while (0)
+#endif
 
 DEVFN uint2 pk4_add(uint2 a, uint2 b) { return make_uint2(a.x + b.x, a.y + b.y); }
 DEVFN uint2 pk4_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y); }
@@ -44,31 +60,67 @@ DEVFN uint32_t me2_coop_sad(const uint32_t *s_win, int col0, int row0, int lane,
 
 __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ __attribute__((aligned(16))) uint32_t s_win[T2_WR * T2_WD];
-    __shared__ __attribute__((aligned(16))) uint2 s_h8[T2_WR * T2_HG]; /* later reused for the current tile */
-    __shared__ __attribute__((aligned(16))) uint2 s_s8[T2_SR * T2_HG];
+    __shared__ __attribute__((aligned(16))) uint2 s_h8[T2_WR * T2_HG];
+    __shared__ __attribute__((aligned(16))) uint4 s_v8[T2_VR * T2_HG];
     __shared__ uint32_t s_list[T2_MBX * T2_MBY][SEA_LIST];
     __shared__ uint32_t s_cnt[T2_MBX * T2_MBY];
-    __shared__ uint16_t s_rank[VENC_ME_CANDS + 1];
+    __shared__ __attribute__((aligned(4))) uint16_t s_rank[VENC_ME_CANDS + 1];
 
     const int item = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * T2_MBX * 16, y0 = blockIdx.y * T2_MBY * 16;
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
-    for (int i = tid; i < VENC_ME_CANDS; i += 512) s_rank[i] = B.me_rank[i];
+    /* every global load whose result is needed late is issued here, ahead of the window staging, so
+     * that no memory round trip sits alone on the critical path: the tie-break ranks (written to LDS
+     * with the window), this lane's current pixels, and last frame's vector of its macroblock */
+    const uint32_t *rank32 = (const uint32_t *)B.me_rank; /* 1089 u16 = 545 dwords (table padded by the launcher) */
+    const uint32_t rk0 = rank32[tid], rk1 = tid + 512 < 545 ? rank32[tid + 512] : 0u;
     const uint16_t *rank = s_rank;
 
     if (tid < T2_MBX * T2_MBY) s_cnt[tid] = 0;
+    const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
+    const int hw = tid >> 5;
+    const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
+    const int mx = blockIdx.x * T2_MBX + mbx, my = blockIdx.y * T2_MBY + mby;
+    const bool mb_valid = mx < g.mbw && my < g.mbh;
+    const int col0 = mbx * 16, row0 = mby * 16;
+    /* this lane's 8 pixels of its macroblock (row l32/2, half l32&1): fetched now, used after the
+     * block sums are built, so the load latency hides behind P0-P2 */
+    uint32_t c0, c1;
+    {
+        const int cy_ = min(y0 + row0 + (l32 >> 1), g.h - 1), cx_ = x0 + col0 + (l32 & 1) * 8;
+        const uint8_t *row = cur + (size_t)cy_ * cstride;
+        if (((g.w & 7) == 0) && cx_ + 8 <= g.w) {
+            const uint2 v = *(const uint2 *)(row + cx_);
+            c0 = v.x, c1 = v.y;
+        } else {
+            c0 = (uint32_t)row[min(cx_, g.w - 1)] | ((uint32_t)row[min(cx_ + 1, g.w - 1)] << 8) |
+                 ((uint32_t)row[min(cx_ + 2, g.w - 1)] << 16) | ((uint32_t)row[min(cx_ + 3, g.w - 1)] << 24);
+            c1 = (uint32_t)row[min(cx_ + 4, g.w - 1)] | ((uint32_t)row[min(cx_ + 5, g.w - 1)] << 8) |
+                 ((uint32_t)row[min(cx_ + 6, g.w - 1)] << 16) | ((uint32_t)row[min(cx_ + 7, g.w - 1)] << 24);
+        }
+    }
+    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
+    const uint32_t prev = B.mvsad_prev[mbidx];
+    ME_STAMP_INIT;
     /* ---- P0: reference window, rows y0-16 .. y0+47, columns x0-16 .. x0+143 (+8 zero bytes) ---- */
     const bool xin = (x0 - 16 >= 0) && (x0 + T2_MBX * 16 + 16 <= g.cw);
     if (xin) {
-        for (int i = tid; i < T2_WR * 10; i += 512) {
-            const int r = i / 10, q = i - r * 10;
-            const int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
-            const uint4 v = *(const uint4 *)(ref + (size_t)ry * rstride + x0 - 16 + 16 * q);
-            uint32_t *d = s_win + r * T2_WD + 4 * q;
-            *(uint2 *)d = make_uint2(v.x, v.y); /* row stride is 8-byte aligned only */
-            *(uint2 *)(d + 2) = make_uint2(v.z, v.w);
+        /* 640 16-byte pieces for 512 threads: both loads of a thread are in flight before the first LDS write */
+        const int i0 = tid, i1 = tid + 512;
+        const int ra = i0 / 10, qa = i0 - ra * 10, rb = i1 / 10, qb = i1 - rb * 10;
+        const bool two = i1 < T2_WR * 10;
+        const uint4 va = *(const uint4 *)(ref + (size_t)clampi(y0 - 16 + ra, 0, g.ch - 1) * rstride + x0 - 16 + 16 * qa);
+        uint4 vb = make_uint4(0, 0, 0, 0);
+        if (two) vb = *(const uint4 *)(ref + (size_t)clampi(y0 - 16 + rb, 0, g.ch - 1) * rstride + x0 - 16 + 16 * qb);
+        uint32_t *da = s_win + ra * T2_WD + 4 * qa;
+        *(uint2 *)da = make_uint2(va.x, va.y); /* row stride is 8-byte aligned only */
+        *(uint2 *)(da + 2) = make_uint2(va.z, va.w);
+        if (two) {
+            uint32_t *db = s_win + rb * T2_WD + 4 * qb;
+            *(uint2 *)db = make_uint2(vb.x, vb.y);
+            *(uint2 *)(db + 2) = make_uint2(vb.z, vb.w);
         }
     } else {
         for (int i = tid; i < T2_WR * 40; i += 512) {
@@ -85,7 +137,10 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
         s_win[tid * T2_WD + 40] = 0;
         s_win[tid * T2_WD + 41] = 0;
     }
+    ((uint32_t *)s_rank)[tid] = rk0;
+    if (tid + 512 < 545) ((uint32_t *)s_rank)[tid + 512] = rk1;
     __syncthreads();
+    ME_STAMP(0);
     /* ---- P1: horizontal 8-sums, four columns per item ---- */
     {   /* thread = (row, run of 5 column groups): 6 sliding-sum instructions give 5 groups of 8-sums */
         const int r = tid >> 3, q0 = (tid & 7) * 5;
@@ -104,54 +159,41 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
             if (q0 + k < T2_HG) s_h8[r * T2_HG + q0 + k] = pk4_add(h4[k], h4[k + 1]);
     }
     __syncthreads();
-    /* ---- P2: vertical 8-sums: 8 segments of up to 8 rows x 39 column groups ---- */
-    if (tid < 8 * T2_HG) {
+    ME_STAMP(1);
+    /* ---- P2: vertical 8-sums, stored as vertical pairs V(x,y) = S8(x,y) | S8(x,y+8) << 16 so that the
+     * bound of a candidate needs two dword reads (left and right 8x8 columns) and no repacking.
+     * 7 segments of 8 rows x 39 column groups; a thread slides down 16 rows of block sums. */
+    if (tid < 7 * T2_HG) {
         const int seg = tid / T2_HG, q = tid - seg * T2_HG;
         const int r0 = seg * 8;
         const uint2 *col = s_h8 + r0 * T2_HG + q;
+        uint2 sr[16];
         uint2 acc = col[0];
 #pragma unroll
         for (int k = 1; k < 8; k++) acc = pk4_add(acc, col[k * T2_HG]);
-        s_s8[r0 * T2_HG + q] = acc;
+        sr[0] = acc;
 #pragma unroll
-        for (int k = 1; k < 8; k++) {
-            if (r0 + k < T2_SR) {
-                acc = pk4_sub(pk4_add(acc, col[(k + 7) * T2_HG]), col[(k - 1) * T2_HG]);
-                s_s8[(r0 + k) * T2_HG + q] = acc;
+        for (int k = 1; k < 16; k++) {
+            if (r0 + k <= T2_VR + 7) acc = pk4_sub(pk4_add(acc, col[(k + 7) * T2_HG]), col[(k - 1) * T2_HG]);
+            sr[k] = acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (r0 + k < T2_VR) {
+                const uint2 lo = sr[k], hi = sr[k + 8];
+                uint4 o;
+                o.x = (lo.x & 0xffffu) | (hi.x << 16);
+                o.y = (lo.x >> 16) | (hi.x & 0xffff0000u);
+                o.z = (lo.y & 0xffffu) | (hi.y << 16);
+                o.w = (lo.y >> 16) | (hi.y & 0xffff0000u);
+                s_v8[(r0 + k) * T2_HG + q] = o;
             }
         }
     }
     __syncthreads();
-    /* ---- current tile (32 rows x 128 bytes) into the space of s_h8 ---- */
-    uint32_t *s_cur = (uint32_t *)s_h8;
-    const bool cur_fast = ((g.w & 15) == 0) && (x0 + T2_MBX * 16 <= g.w);
-    if (cur_fast) {
-        if (tid < 256) {
-            const int r = tid >> 3, q = tid & 7;
-            const uint4 v = *(const uint4 *)(cur + (size_t)min(y0 + r, g.h - 1) * cstride + x0 + 16 * q);
-            *(uint4 *)(s_cur + r * 32 + 4 * q) = v;
-        }
-    } else {
-        for (int i = tid; i < 32 * 32; i += 512) {
-            const int r = i >> 5, d = i & 31;
-            const int xb = x0 + 4 * d;
-            const uint8_t *row = cur + (size_t)min(y0 + r, g.h - 1) * cstride;
-            s_cur[i] = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
-                       ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
-        }
-    }
-    __syncthreads();
-
+    ME_STAMP(2);
     /* ---- per macroblock: one half-wave ---- */
-    const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
-    const int hw = tid >> 5;
-    const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
-    const int mx = blockIdx.x * T2_MBX + mbx, my = blockIdx.y * T2_MBY + mby;
-    const bool mb_valid = mx < g.mbw && my < g.mbh;
-    const int col0 = mbx * 16, row0 = mby * 16;
-
-    const uint32_t c0 = s_cur[(row0 + (l32 >> 1)) * 32 + mbx * 4 + (l32 & 1) * 2];
-    const uint32_t c1 = s_cur[(row0 + (l32 >> 1)) * 32 + mbx * 4 + (l32 & 1) * 2 + 1];
+    ME_STAMP(3);
     uint32_t part = __builtin_amdgcn_sad_u8(c0, 0u, 0u);
     part = __builtin_amdgcn_sad_u8(c1, 0u, part);
     part += (uint32_t)__shfl_xor((int)part, 2);
@@ -159,38 +201,27 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     part += (uint32_t)__shfl_xor((int)part, 8);
     const uint32_t q00 = (uint32_t)__shfl((int)part, hbase | 0), q01 = (uint32_t)__shfl((int)part, hbase | 1);
     const uint32_t q10 = (uint32_t)__shfl((int)part, hbase | 16), q11 = (uint32_t)__shfl((int)part, hbase | 17);
-    const uint32_t ctop = q00 | (q01 << 16), cbot = q10 | (q11 << 16);
+    const uint32_t cleft = q00 | (q10 << 16), cright = q01 | (q11 << 16); /* (top, bottom) sums of the left / right 8x8 columns */
 
-    /* ---- P3: lower bounds.  Lane = window column cx = l32; sums row r serves cy = r (top pair) and cy = r - 8 (bottom pair) */
-    const uint16_t *s8 = (const uint16_t *)s_s8;
+    /* ---- P3: lower bounds.  Lane = window column cx = l32, one register per vertical displacement:
+     * LB = |V_left - (TL,BL)| + |V_right - (TR,BR)|, two v_sad_u16 on packed u16 pairs */
+    const uint32_t *v8 = (const uint32_t *)s_v8;
     uint32_t lb[33];
     {
-        const uint16_t *colp = s8 + row0 * T2_SU + col0 + l32;
+        const uint32_t *colp = v8 + row0 * T2_SU + col0 + l32;
 #pragma unroll
-        for (int r = 0; r < 41; r++) {
-            const uint32_t p = (uint32_t)colp[r * T2_SU] | ((uint32_t)colp[r * T2_SU + 8] << 16);
-            if (r <= 32) lb[r] = __builtin_amdgcn_sad_u16(p, ctop, 0u);
-            if (r >= 8) lb[r - 8] = __builtin_amdgcn_sad_u16(p, cbot, lb[r - 8]);
-        }
+        for (int cy = 0; cy < 33; cy++)
+            lb[cy] = __builtin_amdgcn_sad_u16(colp[cy * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[cy * T2_SU], cleft, 0u));
     }
     uint32_t lbx0, lbx1 = 0xffffffffu; /* column cx = 32: lane l32 owns cy = l32, lane 0 also cy = 32 */
     {
-        const uint16_t *colp = s8 + row0 * T2_SU + col0 + 32;
-        uint32_t p = (uint32_t)colp[l32 * T2_SU] | ((uint32_t)colp[l32 * T2_SU + 8] << 16);
-        uint32_t a = __builtin_amdgcn_sad_u16(p, ctop, 0u);
-        p = (uint32_t)colp[(l32 + 8) * T2_SU] | ((uint32_t)colp[(l32 + 8) * T2_SU + 8] << 16);
-        lbx0 = __builtin_amdgcn_sad_u16(p, cbot, a);
-        if (l32 == 0) {
-            p = (uint32_t)colp[32 * T2_SU] | ((uint32_t)colp[32 * T2_SU + 8] << 16);
-            a = __builtin_amdgcn_sad_u16(p, ctop, 0u);
-            p = (uint32_t)colp[40 * T2_SU] | ((uint32_t)colp[40 * T2_SU + 8] << 16);
-            lbx1 = __builtin_amdgcn_sad_u16(p, cbot, a);
-        }
+        const uint32_t *colp = v8 + row0 * T2_SU + col0 + 32;
+        lbx0 = __builtin_amdgcn_sad_u16(colp[l32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[l32 * T2_SU], cleft, 0u));
+        if (l32 == 0) lbx1 = __builtin_amdgcn_sad_u16(colp[32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[32 * T2_SU], cleft, 0u));
     }
 
+    ME_STAMP(4);
     /* ---- P4: starting points, survivors, evaluation ---- */
-    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
-    const uint32_t prev = B.mvsad_prev[mbidx];
     const int pcx = (int)(int8_t)(prev & 255u) + 16, pcy = (int)(int8_t)((prev >> 8) & 255u) + 16;
     /* third starting point: the candidate with the smallest lower bound */
     uint32_t lmin = (lbx0 << 12) | (uint32_t)(l32 * 33 + 32);
@@ -221,6 +252,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
             if (pos < SEA_LIST) s_list[hw][pos] = (lbx1 << 12) | (uint32_t)(32 * 33 + 32);
         }
     }
+    ME_STAMP(5);
     __syncthreads();
     const uint32_t cnt = s_cnt[hw];
     const bool overflow = cnt > SEA_LIST;
@@ -237,6 +269,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
         bsad = min(bsad, sad);
         best = min(best, (sad << 11) | rank[cy * 33 + cx]);
     }
+    ME_STAMP(6);
     if (l32 == 0 && mb_valid) {
         const uint32_t cand = B.me_cand[best & 2047u];
         const int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
