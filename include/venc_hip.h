@@ -98,6 +98,31 @@ void venc_host_free(void *p);
 int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, const int *out_slots, int is_idr,
                      int frame_num, const int *idr_ids);
 
+/* ---- Slice-parallel multi-GPU mode (BASELINE config 5) ----
+ * One context per GPU codes a band of the picture: `slice_count` consecutive slices starting at
+ * `slice_first` (0, 0 = the whole picture again).  Slices never predict across their borders, so a
+ * band's bitstream is independent of the other bands; only the motion search and the motion
+ * compensation of the NEXT P picture read reconstructed rows of the neighbouring bands (+-16 luma
+ * rows).  After a step that is followed by a P picture the host therefore runs one exchange:
+ *   venc_band_export()  packs this context's band of the reconstruction just written (all rows, or
+ *                       with halo_rows = 16 only its first and last 16 luma / 8 chroma rows) into a
+ *                       contiguous device chunk, [item][Y rows | U rows | V rows];
+ *   RCCL all-gather / broadcast of the chunks (torch.distributed in video-encoder_amd/dist.py,
+ *                       on the stream returned by venc_stream_handle());
+ *   venc_band_import()  unpacks a peer's chunk (the band `slice_first, slice_count` it codes) into
+ *                       this context's reconstruction.
+ * Both are enqueued on the context's main stream: ordered after the step's transform kernels and
+ * before the next step's motion search, no host synchronisation.  The output slot's slice table
+ * keeps n_slices entries; slices outside the band have nbytes = 0.
+ * venc_band_export/import return the chunk bytes per item (> 0) or a negative error. */
+int venc_set_band(venc_ctx *c, int slice_first, int slice_count);
+int venc_band_rows(const venc_ctx *c, int slice_first, int slice_count, int *mb_row0, int *mb_row1);
+size_t venc_band_chunk_bytes(const venc_ctx *c, int mb_rows, int halo_rows);
+int venc_band_export(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride, int halo_rows);
+int venc_band_import(venc_ctx *c, int n_items, const void *d_chunk, size_t item_stride, int slice_first, int slice_count,
+                     int halo_rows);
+void *venc_stream_handle(venc_ctx *c); /* hipStream_t of the main kernel chain */
+
 /* Completion tracking: venc_mark() records an event after everything enqueued
  * so far; venc_wait(ticket) blocks the host until that point. */
 int venc_mark(venc_ctx *c);

@@ -88,6 +88,16 @@ typedef struct x264_param_t {
         int i_device;       /* HIP device ordinal */
         int i_gop_batch;    /* closed GOPs encoded in lock-step (1 = frame-by-frame streaming) */
         int i_gop_base;     /* index of this encoder's first GOP in the whole stream (GOP-sharded multi-GPU runs) */
+        /* slice-parallel multi-GPU mode (BASELINE config 5): this encoder codes only
+         * the slices [i_slice_first, i_slice_first + i_slice_count) of every picture (0, 0 = all) and calls
+         * pf_exchange(p_exchange_user, engine, n_items) after every picture that a P picture follows, so
+         * that the bands' owners can swap reconstructed rows (venc_band_export / RCCL / venc_band_import,
+         * include/venc_hip.h).  The NAL array of a frame then holds this band's slices only (parameter
+         * sets come from the band with slice 0); concatenating the bands' payloads in band order gives the
+         * single-encoder frame byte for byte. */
+        int i_slice_first, i_slice_count;
+        int (*pf_exchange)(void *user, void *engine, int n_items);
+        void *p_exchange_user;
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;

@@ -70,6 +70,15 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int stride_y, const uint8_t *u
                     const uint8_t *v, int stride_v, uint8_t *out, size_t out_cap, orc_nal *nals,
                     int *nal_count, int *is_idr);
 
+/* Slice-parallel stand-in (tests of the multi-GPU band mode):
+ * orc_enc_set_band restricts the encoder to slices [first, first+count) -- motion search,
+ * transform and entropy coding of those slices only; parameter sets are emitted only by the band
+ * that holds slice 0.  orc_enc_import_rows overwrites MB rows [row0, row1) of the reconstruction
+ * of the last frame with a peer's rows (tight planes of the coded width) and rebuilds the padded
+ * reference, which is what the exchange step of the band mode does on the GPU. */
+int orc_enc_set_band(orc_enc *e, int slice_first, int slice_count);
+int orc_enc_import_rows(orc_enc *e, int mb_row0, int mb_row1, const uint8_t *y, const uint8_t *u, const uint8_t *v);
+
 /* Introspection of the last encoded frame (for kernel-level parity tests). */
 int orc_enc_mb_width(const orc_enc *e);
 int orc_enc_mb_height(const orc_enc *e);

@@ -308,6 +308,7 @@ struct orc_enc {
     size_t slice_cap;
     size_t *slice_len;
     uint8_t *esc_buf;
+    int band_s0, band_s1; /* slices coded by this instance */
 };
 
 static int pick_level(int mbs, int fps_num, int fps_den) {
@@ -370,6 +371,8 @@ orc_enc *orc_enc_open(const orc_params *p) {
     for (int dy = -16; dy <= 16; dy++)
         for (int dx = -16; dx <= 16; dx++) e->rank[(dy + 16) * 33 + dx + 16] = (uint16_t)orc_me_rank(dx, dy);
     for (int i = 0; i < 48; i++) e->cbp_to_code[orc_golomb_to_inter_cbp[i]] = (uint8_t)i;
+    e->band_s0 = 0;
+    e->band_s1 = e->p.n_slices;
     e->slice_buf = (uint8_t **)calloc((size_t)e->p.n_slices, sizeof(uint8_t *));
     e->slice_len = (size_t *)calloc((size_t)e->p.n_slices, sizeof(size_t));
     {
@@ -929,6 +932,29 @@ static void write_slice_header(const orc_enc *e, bw_t *b, int first_mb, int idr)
     bw_ue(b, 1);         /* disable_deblocking_filter_idc */
 }
 
+int orc_enc_set_band(orc_enc *e, int slice_first, int slice_count) {
+    if (slice_first < 0 || slice_count < 1 || slice_first + slice_count > e->p.n_slices) return -1;
+    e->band_s0 = slice_first;
+    e->band_s1 = slice_first + slice_count;
+    return 0;
+}
+
+static void repad(orc_enc *e) {
+    pad_plane(e->refp[0], e->refp_stride[0], LPAD, e->rec[0], e->cw, e->ch);
+    pad_plane(e->refp[1], e->refp_stride[1], CPAD, e->rec[1], e->cw / 2, e->ch / 2);
+    pad_plane(e->refp[2], e->refp_stride[2], CPAD, e->rec[2], e->cw / 2, e->ch / 2);
+}
+
+int orc_enc_import_rows(orc_enc *e, int mb_row0, int mb_row1, const uint8_t *y, const uint8_t *u, const uint8_t *v) {
+    if (mb_row0 < 0 || mb_row1 > e->mbh || mb_row0 >= mb_row1 || !y || !u || !v) return -1;
+    const int n = mb_row1 - mb_row0;
+    memcpy(e->rec[0] + (size_t)mb_row0 * 16 * e->cw, y, (size_t)n * 16 * e->cw);
+    memcpy(e->rec[1] + (size_t)mb_row0 * 8 * (e->cw / 2), u, (size_t)n * 8 * (e->cw / 2));
+    memcpy(e->rec[2] + (size_t)mb_row0 * 8 * (e->cw / 2), v, (size_t)n * 8 * (e->cw / 2));
+    repad(e);
+    return 0;
+}
+
 long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int su, const uint8_t *v, int sv,
                     uint8_t *out, size_t out_cap, orc_nal *nals, int *nal_count, int *is_idr) {
     int idr = (e->frame_idx % e->p.keyint) == 0;
@@ -936,18 +962,17 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
     ingest_plane(e->cur[0], e->cw, e->ch, y, sy, e->p.width, e->p.height);
     ingest_plane(e->cur[1], e->cw / 2, e->ch / 2, u, su, e->p.width / 2, e->p.height / 2);
     ingest_plane(e->cur[2], e->cw / 2, e->ch / 2, v, sv, e->p.width / 2, e->p.height / 2);
-    int ns = e->p.n_slices;
 
 #ifdef _OPENMP
     omp_set_num_threads(e->p.threads);
 #endif
     if (!idr) {
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int my = 0; my < e->mbh; my++)
+        for (int my = e->slice_rows[e->band_s0]; my < e->slice_rows[e->band_s1]; my++)
             for (int mx = 0; mx < e->mbw; mx++) me_mb(e, mx, my);
     }
 #pragma omp parallel for schedule(dynamic, 1)
-    for (int s = 0; s < ns; s++) {
+    for (int s = e->band_s0; s < e->band_s1; s++) {
         int r0 = e->slice_rows[s], r1 = e->slice_rows[s + 1];
         for (int my = r0; my < r1; my++)
             for (int mx = 0; mx < e->mbw; mx++) {
@@ -971,14 +996,14 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
         bw_trailing(&b);
         e->slice_len[s] = b.overflow ? (size_t)-1 : b.pos;
     }
-    for (int s = 0; s < ns; s++)
+    for (int s = e->band_s0; s < e->band_s1; s++)
         if (e->slice_len[s] == (size_t)-1) return -2;
 
     /* NAL assembly: contiguous, 4-byte length prefixes, parameter sets first
      * (consumer contract av_encode.c:670-751, :802-811) */
     size_t o = 0;
     int n = 0;
-    if (idr) {
+    if (idr && e->band_s0 == 0) {
         uint8_t rbsp[128];
         size_t k = write_sps(e, rbsp, sizeof(rbsp));
         if (o + k * 2 + 8 > out_cap) return -1;
@@ -991,7 +1016,7 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
         nals[n++] = (orc_nal){8, 3, o, sz};
         o += sz;
     }
-    for (int s = 0; s < ns; s++) {
+    for (int s = e->band_s0; s < e->band_s1; s++) {
         if (o + e->slice_len[s] * 3 / 2 + 8 > out_cap || n >= ORC_MAX_NALS) return -1;
         size_t sz = write_nal(out + o, idr ? 3 : 2, idr ? 5 : 1, e->slice_buf[s], e->slice_len[s]);
         nals[n++] = (orc_nal){idr ? 5 : 1, idr ? 3 : 2, o, sz};

@@ -56,6 +56,8 @@ def lib():
         L.orc_enc_mb_height.argtypes = [C.c_void_p]
         L.orc_enc_recon.restype = C.POINTER(C.c_uint8)
         L.orc_enc_recon.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        L.orc_enc_set_band.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_enc_import_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_fdct4x4.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_idct4x4.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_quant.argtypes = [C.c_int] * 4
@@ -123,6 +125,18 @@ class Encoder:
         nals = [(self._nals[i].type, self._nals[i].ref_idc, self._nals[i].offset, self._nals[i].size)
                 for i in range(n.value)]
         return Frame(self._out[:r].tobytes(), nals, bool(idr.value))
+
+    # --- slice-parallel stand-in (orc.h) ---
+    def set_band(self, slice_first, slice_count):
+        if self.L.orc_enc_set_band(self.h, slice_first, slice_count) != 0:
+            raise ValueError("orc_enc_set_band: bad slice range")
+
+    def import_rows(self, mb_row0, mb_row1, y, u, v):
+        y, u, v = (np.ascontiguousarray(a, dtype=np.uint8) for a in (y, u, v))
+        n = mb_row1 - mb_row0
+        assert y.shape == (n * 16, self.mbw * 16) and u.shape == v.shape == (n * 8, self.mbw * 8)
+        if self.L.orc_enc_import_rows(self.h, mb_row0, mb_row1, y.ctypes.data, u.ctypes.data, v.ctypes.data) != 0:
+            raise ValueError("orc_enc_import_rows: bad row range")
 
     # --- introspection of the last frame ---
     def mv(self):

@@ -63,3 +63,128 @@ def test_two_rank_gloo_gop_sharding_reproduces_the_single_stream():
         assert p.exitcode == 0
     assert same and n > 1000
     assert slowest == 2.0
+
+
+# ----------------------------------------------------------------------------- slice-parallel mode
+def test_slice_band_partition():
+    d = importlib.import_module("video-encoder_amd.dist")
+    for n_slices, world in ((8, 1), (8, 2), (8, 3), (8, 8), (5, 2), (17, 4)):
+        cover = []
+        for r in range(world):
+            s0, cnt = d.slice_band(n_slices, world, r)
+            assert cnt >= 1
+            cover += list(range(s0, s0 + cnt))
+        assert cover == list(range(n_slices))
+    with pytest.raises(ValueError):
+        d.slice_band(4, 8, 0)
+    assert d.interleave_bands([[b"a", b"b"], [b"c", b"d"]]) == [b"ac", b"bd"]
+
+
+class OraclePort:
+    """BandExchange chunk access on the CPU oracle standing in for the GPU engine: same chunk layout as
+    venc_band_export ([item][Y rows | U rows | V rows]; halo mode: first and last MB row of the band)."""
+
+    def alloc(self, nbytes):
+        import torch
+        return torch.zeros(nbytes, dtype=torch.uint8)
+
+    def rows_of(self, enc, slice_first, slice_count):
+        rows = enc.slice_rows()
+        return int(rows[slice_first]), int(rows[slice_first + slice_count])
+
+    @staticmethod
+    def _segments(r0, r1, halo_rows):
+        """MB-row runs carried for the band [r0, r1)."""
+        if halo_rows == 0 or 2 * (halo_rows // 16) >= r1 - r0:
+            return [(r0, r1)]
+        k = halo_rows // 16
+        return [(r0, r0 + k), (r1 - k, r1)]
+
+    def chunk_bytes(self, enc, mb_rows, halo_rows):
+        n = sum(b - a for a, b in self._segments(0, mb_rows, halo_rows))
+        return n * 16 * enc.mbw * 16 * 3 // 2
+
+    def export(self, enc, n_items, chunk, item_stride, halo_rows):
+        import numpy as np
+        import torch
+        assert n_items == 1
+        r0, r1 = self.rows_of(enc, *self.band)
+        planes = enc.recon()
+        out = []
+        for p, sub in ((0, 16), (1, 8), (2, 8)):
+            for a, b in self._segments(r0, r1, halo_rows):
+                out.append(planes[p][a * sub:b * sub].reshape(-1))
+        flat = np.concatenate(out)
+        chunk[:flat.size] = torch.from_numpy(flat)
+
+    def import_(self, enc, n_items, chunk, item_stride, slice_first, slice_count, halo_rows):
+        r0, r1 = self.rows_of(enc, slice_first, slice_count)
+        segs = self._segments(r0, r1, halo_rows)
+        data = chunk.numpy()
+        cw = enc.mbw * 16
+        o = 0
+        parts = {}
+        for p, sub, w in ((0, 16, cw), (1, 8, cw // 2), (2, 8, cw // 2)):
+            for a, b in segs:
+                n = (b - a) * sub * w
+                parts[(p, a)] = data[o:o + n].reshape((b - a) * sub, w)
+                o += n
+        for a, b in segs:
+            enc.import_rows(a, b, parts[(0, a)], parts[(1, a)], parts[(2, a)])
+
+    def sync(self, enc):
+        pass
+
+
+def _band_worker(rank, world, port, q, halo_rows, n_slices):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import orc_py
+    from conftest import noise_frames
+    d = importlib.import_module("video-encoder_amd.dist")
+    d.init_from_env("gloo")
+    w, h, n_frames, keyint = 96, 112, 9, 4  # 7 MB rows: uneven bands
+    clip = noise_frames(w, h, n_frames, seed=5)
+    s0, cnt = d.slice_band(n_slices, world, rank)
+    enc = orc_py.Encoder(w, h, qp=28, n_slices=n_slices, keyint=keyint)
+    enc.set_band(s0, cnt)
+    oport = OraclePort()
+    oport.band = (s0, cnt)
+    xc = d.BandExchange(oport, n_slices, world, rank, halo_rows=halo_rows)
+    mine = []
+    for f in range(n_frames):
+        mine.append(enc.encode(*clip[f]).data)
+        if (f + 1) % keyint != 0:  # a P picture follows (same rule as x264_shim.c launch_pending)
+            xc(enc, 1)
+    parts = d.gather_frames(mine)
+    if rank == 0:
+        ref = orc_py.Encoder(w, h, qp=28, n_slices=n_slices, keyint=keyint)
+        single = [ref.encode(*clip[f]).data for f in range(n_frames)]
+        whole = d.interleave_bands(parts)
+        q.put(([a == b for a, b in zip(whole, single)], xc.exchanges, sum(len(x) for x in whole)))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,halo_rows,n_slices", [(2, 0, 5), (3, 16, 4)])
+def test_gloo_slice_parallel_bands_reproduce_the_single_stream(world, halo_rows, n_slices):
+    """Slice-parallel mode (BASELINE config 5) on CPU: every rank codes its band of each picture with the
+    oracle standing in for the engine, BandExchange swaps the reconstructed rows over gloo, and the
+    band-ordered concatenation equals the single-encoder stream byte for byte, frame by frame."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() + 7 * world) % 40
+    procs = [ctx.Process(target=_band_worker, args=(r, world, port, q, halo_rows, n_slices)) for r in range(world)]
+    for p in procs:
+        p.start()
+    same, exchanges, nbytes = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(same), same
+    assert exchanges == 7 and nbytes > 2000  # 9 frames, keyint 4: exchange after frames 0,1,2,4,5,6,8

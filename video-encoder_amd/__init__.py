@@ -72,8 +72,13 @@ class _Rc(C.Structure):
     _fields_ = [("i_rc_method", C.c_int), ("i_qp_constant", C.c_int), ("f_rf_constant", C.c_float)]
 
 
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
+
+
 class _Hip(C.Structure):
-    _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int)]
+    _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int),
+                ("i_slice_first", C.c_int), ("i_slice_count", C.c_int), ("pf_exchange", EXCHANGE_FN),
+                ("p_exchange_user", C.c_void_p)]
 
 
 class X264Param(C.Structure):
@@ -147,6 +152,14 @@ def hip_lib():
         L.venc_profile_name.restype = C.c_char_p
         L.venc_profile_name.argtypes = [C.c_int]
         L.venc_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.venc_set_band.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.venc_band_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.venc_band_chunk_bytes.restype = C.c_size_t
+        L.venc_band_chunk_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.venc_band_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+        L.venc_band_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.venc_stream_handle.restype = C.c_void_p
+        L.venc_stream_handle.argtypes = [C.c_void_p]
         _hip = L
     return _hip
 
@@ -203,10 +216,23 @@ class Engine:
         self.n_slices = self.L.venc_n_slices(h)
         self.frame_bytes = self.L.venc_frame_bytes(h)
 
+    @classmethod
+    def view(cls, handle):
+        """Non-owning view of a venc_ctx* that somebody else opened (the x264 shim's engine)."""
+        self = cls.__new__(cls)
+        self.L = hip_lib()
+        self.h = C.c_void_p(handle)
+        self._borrowed = True
+        self.mbw, self.mbh = self.L.venc_mb_width(self.h), self.L.venc_mb_height(self.h)
+        self.nmb = self.mbw * self.mbh
+        self.n_slices = self.L.venc_n_slices(self.h)
+        self.frame_bytes = self.L.venc_frame_bytes(self.h)
+        return self
+
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_borrowed", False):
             self.L.venc_close(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.close()
@@ -254,6 +280,29 @@ class Engine:
             out.append(bytes(np.ctypeslib.as_array(f.data, (f.total_bytes,))[sl.byte_off:sl.byte_off + sl.nbytes]))
         return out
 
+    # ---- slice-parallel multi-GPU mode (include/venc_hip.h, "Slice-parallel multi-GPU mode")
+    def set_band(self, slice_first=0, slice_count=0):
+        self._ok(self.L.venc_set_band(self.h, slice_first, slice_count), "venc_set_band")
+
+    def band_rows(self, slice_first, slice_count):
+        r0, r1 = C.c_int(0), C.c_int(0)
+        self._ok(self.L.venc_band_rows(self.h, slice_first, slice_count, C.byref(r0), C.byref(r1)), "venc_band_rows")
+        return r0.value, r1.value
+
+    def band_chunk_bytes(self, mb_rows, halo_rows=0):
+        return self.L.venc_band_chunk_bytes(self.h, mb_rows, halo_rows)
+
+    def band_export(self, n_items, dev_ptr, item_stride, halo_rows=0):
+        return self._ok(self.L.venc_band_export(self.h, n_items, C.c_void_p(dev_ptr), item_stride, halo_rows),
+                        "venc_band_export")
+
+    def band_import(self, n_items, dev_ptr, item_stride, slice_first, slice_count, halo_rows=0):
+        return self._ok(self.L.venc_band_import(self.h, n_items, C.c_void_p(dev_ptr), item_stride, slice_first,
+                                                slice_count, halo_rows), "venc_band_import")
+
+    def stream_handle(self):
+        return self.L.venc_stream_handle(self.h)
+
     def debug(self, what, item=0):
         cw, ch = self.mbw * 16, self.mbh * 16
         shapes = {0: ((self.nmb,), np.uint32), 1: ((self.nmb, 27, 16), np.int16), 2: ((self.nmb, 32), np.uint8),
@@ -285,7 +334,10 @@ class X264Encoder:
     """Mirror of the reference's x264_context_t usage (av_encode.c:369-444, :543-547, :968-975, :1076-1083)."""
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
-                 tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0):
+                 tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0,
+                 slice_first=0, slice_count=0, exchange=None):
+        """slice_first / slice_count / exchange: slice-parallel multi-GPU mode (include/x264.h, hip extension);
+        exchange(engine_view, n_items) is called after every picture that a P picture follows."""
         self.L = x264_lib()
         p = X264Param()
         if self.L.x264_param_default_preset(C.byref(p), preset.encode() if preset else None,
@@ -301,6 +353,18 @@ class X264Encoder:
             p.rc.i_rc_method, p.rc.i_qp_constant = X264_RC_CQP, qp
         p.i_keyint_max, p.i_slice_count = keyint, slices
         p.hip.i_device, p.hip.i_gop_batch, p.hip.i_gop_base = device, gop_batch, gop_base
+        p.hip.i_slice_first, p.hip.i_slice_count = slice_first, slice_count
+        self._exchange_error = None
+        if exchange is not None:
+            def _xc(user, engine_ptr, n_items):
+                try:
+                    exchange(Engine.view(engine_ptr), n_items)
+                    return 0
+                except BaseException as e:  # never unwind through the C frames
+                    self._exchange_error = e
+                    return -1
+            self._exchange_cb = EXCHANGE_FN(_xc)  # keep alive as long as the encoder
+            p.hip.pf_exchange = self._exchange_cb
         if self.L.x264_param_apply_profile(C.byref(p), profile.encode() if profile else None) != 0:
             raise ValueError("x264: failed to apply profile %s" % profile)
         self.param = p
@@ -324,6 +388,12 @@ class X264Encoder:
     def __del__(self):
         self.close()
 
+    def _error(self, msg):
+        e = VencError(msg)
+        if getattr(self, "_exchange_error", None) is not None:  # raised inside the band-exchange callback
+            e.__cause__ = self._exchange_error
+        return e
+
     def _collect(self, size, nals, n):
         base = C.addressof(nals[0].p_payload.contents)
         payload = C.string_at(base, size)
@@ -342,7 +412,7 @@ class X264Encoder:
         size = self.L.x264_encoder_encode(self.h, C.byref(nals), C.byref(n), C.byref(self.pic_in),
                                           C.byref(self.pic_out))
         if size < 0:
-            raise VencError("x264: encoder error")
+            raise self._error("x264: encoder error")
         return self._collect(size, nals, n.value) if size > 0 else None
 
     def delayed_frames(self):
@@ -355,7 +425,7 @@ class X264Encoder:
             nals, n = C.POINTER(X264Nal)(), C.c_int(0)
             size = self.L.x264_encoder_encode(self.h, C.byref(nals), C.byref(n), None, C.byref(self.pic_out))
             if size < 0:
-                raise VencError("x264: encoder error")
+                raise self._error("x264: encoder error")
             if size > 0:
                 out.append(self._collect(size, nals, n.value))
         return out
@@ -373,7 +443,7 @@ class X264Encoder:
         r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts,
                                              C.cast(cb, C.c_void_p), None)
         if r < 0:
-            raise VencError("x264_venc_encode_resident failed: %s" % hip_lib().venc_last_error().decode())
+            raise self._error("x264_venc_encode_resident failed: %s" % hip_lib().venc_last_error().decode())
         return r
 
     def encode_resident_tally(self, dev_ptr, frame_stride, n_frames, first_pts=0):
@@ -383,7 +453,7 @@ class X264Encoder:
         r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts, fn,
                                              C.cast(C.pointer(t), C.c_void_p))
         if r != n_frames:
-            raise VencError("x264_venc_encode_resident delivered %d of %d frames: %s" % (
+            raise self._error("x264_venc_encode_resident delivered %d of %d frames: %s" % (
                 r, n_frames, hip_lib().venc_last_error().decode()))
         return t
 

@@ -27,9 +27,9 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
               : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                         : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
-    const int mb_raw = blockIdx.x * 256 + tid;
-    const bool valid = mb_raw < g.nmb;
-    const int mb = valid ? mb_raw : 0;
+    const int mb_raw = S.mb0 + blockIdx.x * 256 + tid;
+    const bool valid = mb_raw < S.mb1;
+    const int mb = valid ? mb_raw : S.mb0;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int srow = slice_first_row_of(g, my);
     const bool aL = mx > 0, aT = my > srow;

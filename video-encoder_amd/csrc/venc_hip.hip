@@ -59,6 +59,8 @@ struct venc_ctx {
     int intra_waves;
     int max_slice_mbs;
     int steps_done;
+    int band_s0, band_s1; /* slices coded by this context (venc_set_band); whole picture by default */
+    int slice_rows[VENC_MAX_SLICES + 1];
     int cavlc_legacy; /* VENC_CAVLC=legacy: half-wave-per-macroblock k_cavlc for P pictures too */
     int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
     int me_mode;  /* 0 tile (default): successive elimination, sums built in-kernel; 1 plane: sums from k_refsum;
@@ -234,6 +236,9 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         }
         rows[g.n_slices] = r;
     }
+    memcpy(c->slice_rows, rows, sizeof(int) * (g.n_slices + 1));
+    c->band_s0 = 0;
+    c->band_s1 = g.n_slices;
     c->intra_waves = maxrows < INTRA_MAX_WAVES ? maxrows : INTRA_MAX_WAVES;
     c->max_slice_mbs = maxrows * g.mbw;
     OPEN_OK(hipMalloc(&c->d_slice_rows, sizeof(int) * (g.n_slices + 1)));
@@ -416,6 +421,13 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.is_idr = is_idr ? 1 : 0;
     S.frame_num = frame_num;
     S.parity = c->parity;
+    S.slice0 = c->band_s0;
+    S.slice1 = c->band_s1;
+    S.row0 = c->slice_rows[c->band_s0];
+    S.row1 = c->slice_rows[c->band_s1];
+    S.mb0 = S.row0 * c->g.mbw;
+    S.mb1 = S.row1 * c->g.mbw;
+    const int band_rows = S.row1 - S.row0, band_mbs = S.mb1 - S.mb0, band_slices = S.slice1 - S.slice0;
     for (int i = 0; i < n_items; i++) {
         if (in_slots[i] < 0 || in_slots[i] >= c->in_frames || out_slots[i] < 0 || out_slots[i] >= c->cfg.out_slots) {
             SET_ERR("venc_encode_step: slot out of range (item %d: in %d, out %d)", i, in_slots[i], out_slots[i]);
@@ -437,17 +449,17 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     if (c->overlap && c->side_used[p]) HIP_OK(hipStreamWaitEvent(s1, c->ev_side[p], 0)); /* parity buffers free again */
     if (is_idr) {
         prof_begin(c, KID_INTRA, s1);
-        hipLaunchKernelGGL(k_intra, dim3(g.n_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
+        hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
         prof_end(c, s1);
     } else {
         if (c->me_mode == 0) HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
         if (c->me_mode == 2)
-            hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, band_rows, n_items), dim3(256), 0, s1, g, b, S);
         else if (c->me_mode == 1)
             hipLaunchKernelGGL(k_me, dim3((g.mbw + ME_TILE - 1) / ME_TILE, g.mbh, n_items), dim3(256), 0, s1, g, b, S);
         else
-            hipLaunchKernelGGL(k_me_tile, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (g.mbh + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
+            hipLaunchKernelGGL(k_me_tile, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
                                s1, g, b, S);
         prof_end(c, s1);
         if (c->me_mode == 0) {
@@ -457,14 +469,14 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         }
         if (c->inter_legacy) {
             prof_begin(c, KID_INTER, s1);
-            hipLaunchKernelGGL(k_inter, dim3((g.nmb + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_inter, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
         } else {
             prof_begin(c, KID_INTER, s1);
-            hipLaunchKernelGGL(k_inter_luma, dim3((g.nmb + 15) / 16, 1, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_inter_luma, dim3((band_mbs + 15) / 16, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
             prof_begin(c, KID_INTER_C, s1);
-            hipLaunchKernelGGL(k_inter_chroma, dim3((g.nmb + 31) / 32, 1, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_inter_chroma, dim3((band_mbs + 31) / 32, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
         }
     }
@@ -480,9 +492,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     }
     prof_begin(c, KID_CAVLC, s2);
     if (is_idr || c->cavlc_legacy)
-        hipLaunchKernelGGL(k_cavlc, dim3((g.nmb + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
+        hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
     else
-        hipLaunchKernelGGL(k_cavlc_p, dim3((g.nmb + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S);
+        hipLaunchKernelGGL(k_cavlc_p, dim3((band_mbs + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S);
     prof_end(c, s2);
     if (c->overlap) {
         HIP_OK(hipEventRecord(c->ev_side[p], s2));
@@ -492,7 +504,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, s2, g, b, S, c->d_slice);
     prof_end(c, s2);
     prof_begin(c, KID_PACK, s2);
-    hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, g.n_slices, n_items), dim3(256), 0, s2, g, b, S,
+    hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, band_slices, n_items), dim3(256), 0, s2, g, b, S,
                        (const venc_slice_out *)c->d_slice);
     prof_end(c, s2);
     HIP_OK(hipGetLastError());
@@ -500,6 +512,98 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     c->steps_done++;
     return 0;
 }
+
+/* ---------------------------------------------------------------- slice-parallel multi-GPU mode */
+extern "C" int venc_set_band(venc_ctx *c, int slice_first, int slice_count) {
+    if (slice_first == 0 && slice_count == 0) slice_count = c->g.n_slices;
+    if (slice_first < 0 || slice_count < 1 || slice_first + slice_count > c->g.n_slices) {
+        SET_ERR("venc_set_band: slices [%d, %d) outside 0..%d", slice_first, slice_first + slice_count, c->g.n_slices);
+        return -1;
+    }
+    if ((c->me_mode == 1 || c->inter_legacy) && slice_count != c->g.n_slices) {
+        SET_ERR("venc_set_band: the diagnostic kernels (VENC_ME=plane, VENC_INTER=legacy) code whole pictures only");
+        return -1;
+    }
+    c->band_s0 = slice_first;
+    c->band_s1 = slice_first + slice_count;
+    return 0;
+}
+
+extern "C" int venc_band_rows(const venc_ctx *c, int slice_first, int slice_count, int *mb_row0, int *mb_row1) {
+    if (slice_first < 0 || slice_count < 1 || slice_first + slice_count > c->g.n_slices) {
+        SET_ERR("venc_band_rows: slices [%d, %d) outside 0..%d", slice_first, slice_first + slice_count, c->g.n_slices);
+        return -1;
+    }
+    if (mb_row0) *mb_row0 = c->slice_rows[slice_first];
+    if (mb_row1) *mb_row1 = c->slice_rows[slice_first + slice_count];
+    return 0;
+}
+
+/* luma rows carried per band: the whole band, or (halo_rows > 0) its first and last halo_rows rows */
+static int band_job(const venc_ctx *c, int row0, int row1, int halo_rows, venc_band_job *J) {
+    const venc_geom &g = c->g;
+    if (halo_rows < 0 || (halo_rows & 15)) return -1;
+    const int ly0 = row0 * 16, ly1 = row1 * 16;
+    const uint32_t ysz = (uint32_t)g.cw * g.ch;
+    memset(J, 0, sizeof(*J));
+    uint32_t off = 0;
+    for (int plane = 0; plane < 3; plane++) {
+        const int sh = plane ? 1 : 0;
+        const uint32_t pw = (uint32_t)(g.cw >> sh), pbase = plane == 0 ? 0u : plane == 1 ? ysz : ysz + ysz / 4;
+        const int y0 = ly0 >> sh, y1 = ly1 >> sh, hr = halo_rows >> sh;
+        if (halo_rows == 0 || 2 * hr >= y1 - y0) { /* the whole band */
+            J->seg[J->n_seg++] = (venc_band_seg){pbase + (uint32_t)y0 * pw, off, (uint32_t)(y1 - y0) * pw};
+            off += (uint32_t)(y1 - y0) * pw;
+        } else {
+            J->seg[J->n_seg++] = (venc_band_seg){pbase + (uint32_t)y0 * pw, off, (uint32_t)hr * pw};
+            off += (uint32_t)hr * pw;
+            J->seg[J->n_seg++] = (venc_band_seg){pbase + (uint32_t)(y1 - hr) * pw, off, (uint32_t)hr * pw};
+            off += (uint32_t)hr * pw;
+        }
+    }
+    return (int)off;
+}
+
+extern "C" size_t venc_band_chunk_bytes(const venc_ctx *c, int mb_rows, int halo_rows) {
+    venc_band_job J;
+    if (mb_rows < 1 || mb_rows > c->g.mbh) return 0;
+    const int n = band_job(c, 0, mb_rows, halo_rows, &J);
+    return n < 0 ? 0 : (size_t)n;
+}
+
+static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride, int row0, int row1, int halo_rows, int to_chunk) {
+    venc_band_job J;
+    const int bytes = band_job(c, row0, row1, halo_rows, &J);
+    if (n_items < 1 || n_items > c->cfg.max_items || !d_chunk || bytes < 0 || (item_stride & 15) || item_stride < (size_t)bytes ||
+        (((uintptr_t)d_chunk) & 15)) {
+        SET_ERR("venc_band_%s: bad arguments (items %d, stride %zu, chunk %d bytes, halo %d)", to_chunk ? "export" : "import", n_items,
+                item_stride, bytes, halo_rows);
+        return -1;
+    }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    J.to_chunk = to_chunk;
+    J.item_stride = item_stride;
+    uint32_t big = 0;
+    for (int i = 0; i < J.n_seg; i++) big = J.seg[i].bytes > big ? J.seg[i].bytes : big;
+    int blocks = (int)((big / 16 + 1023) / 1024); /* four trips per lane */
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_band_copy, dim3(blocks, J.n_seg, n_items), dim3(256), 0, c->stream, c->b, c->parity ^ 1, J, (uint8_t *)d_chunk);
+    HIP_OK(hipGetLastError());
+    return bytes;
+}
+
+extern "C" int venc_band_export(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride, int halo_rows) {
+    return band_copy(c, n_items, d_chunk, item_stride, c->slice_rows[c->band_s0], c->slice_rows[c->band_s1], halo_rows, 1);
+}
+
+extern "C" int venc_band_import(venc_ctx *c, int n_items, const void *d_chunk, size_t item_stride, int slice_first, int slice_count,
+                                int halo_rows) {
+    int r0, r1;
+    if (venc_band_rows(c, slice_first, slice_count, &r0, &r1) != 0) return -1;
+    return band_copy(c, n_items, (void *)d_chunk, item_stride, r0, r1, halo_rows, 0);
+}
+
+extern "C" void *venc_stream_handle(venc_ctx *c) { return (void *)c->stream; }
 
 extern "C" int venc_mark(venc_ctx *c) {
     const int t = c->ev_next;

@@ -68,9 +68,9 @@ DEVFN void load_cur4x4(const uint8_t *cur, int cstride, int pw, int ph, int px, 
 __global__ __launch_bounds__(256) void k_inter_luma(venc_geom g, venc_bufs B, venc_step S) {
     const int item = blockIdx.z, tid = threadIdx.x;
     const int lane = tid & 63, blk = lane & 15, gbase = lane & 48;
-    const int mb_raw = blockIdx.x * 16 + (tid >> 4);
-    const bool valid = mb_raw < g.nmb;
-    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mb_raw = S.mb0 + blockIdx.x * 16 + (tid >> 4);
+    const bool valid = mb_raw < S.mb1;
+    const int mb = valid ? mb_raw : S.mb1 - 1;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
     const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256) void k_inter_luma(venc_geom g, venc_bufs B, ve
 __global__ __launch_bounds__(256) void k_inter_chroma(venc_geom g, venc_bufs B, venc_step S) {
     const int item = blockIdx.z, tid = threadIdx.x;
     const int lane = tid & 63, k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
-    const int mb_raw = blockIdx.x * 32 + (tid >> 3);
-    const bool valid = mb_raw < g.nmb;
-    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mb_raw = S.mb0 + blockIdx.x * 32 + (tid >> 3);
+    const bool valid = mb_raw < S.mb1;
+    const int mb = valid ? mb_raw : S.mb1 - 1;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
     const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_me_dense(venc_geom g, venc_bufs B, venc
     __shared__ uint32_t s_cur[16 * ME_TILE * 4];
     __shared__ uint16_t s_rank[VENC_ME_CANDS];
 
-    const int item = blockIdx.z, my = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
+    const int item = blockIdx.z, my = S.row0 + blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
     const int x0 = tx * ME_TILE * 16, y0 = my * 16;
     int rstride;
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
@@ -371,9 +371,9 @@ DEVFN void mb_store(int l32, bool valid, const mb_lane_out &o, int16_t *lv_mb, v
 __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_step S) {
     const int item = blockIdx.z, tid = threadIdx.x;
     const int lane = tid & 63, l32 = lane & 31, base = lane & 32;
-    const int mb_raw = blockIdx.x * 8 + (tid >> 5);
-    const bool valid = mb_raw < g.nmb;
-    const int mb = valid ? mb_raw : g.nmb - 1;
+    const int mb_raw = S.mb0 + blockIdx.x * 8 + (tid >> 5);
+    const bool valid = mb_raw < S.mb1;
+    const int mb = valid ? mb_raw : S.mb1 - 1;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const bool luma = l32 < 16;
     const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
@@ -516,7 +516,7 @@ DEVFN void load_cur_rows(const uint8_t *cur, int cstride, int pw, int ph, int px
 
 __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ int s_bot[INTRA_MAX_WAVES][4][5];
-    const int item = blockIdx.z, s = blockIdx.x, tid = threadIdx.x;
+    const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
     const int nw = blockDim.x >> 6;
     const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31;
     const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
@@ -737,9 +737,9 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
               : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                         : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
-    const int mb_raw = blockIdx.x * CAVLC_MBS + team;
-    const bool valid = mb_raw < g.nmb;
-    const int mb = valid ? mb_raw : 0;
+    const int mb_raw = S.mb0 + blockIdx.x * CAVLC_MBS + team;
+    const bool valid = mb_raw < S.mb1;
+    const int mb = valid ? mb_raw : S.mb0;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int srow = slice_first_row_of(g, my);
     const bool aL = mx > 0, aT = my > srow;
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(1024) void k_scan(venc_geom g, venc_bufs B, venc_st
     const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
     uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     /* one wave per slice (round-robin): 64 macroblocks per DPP scan, running total carried in a scalar */
-    for (int s = wv; s < g.n_slices; s += 16) {
+    for (int s = S.slice0 + wv; s < S.slice1; s += 16) {
         const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
         uint32_t running = 0;
         for (int c0 = first; c0 < last; c0 += 64 * 16) { /* 16 loads in flight per lane, then 16 register scans */
@@ -902,7 +902,8 @@ __global__ __launch_bounds__(1024) void k_scan(venc_geom g, venc_bufs B, venc_st
         venc_slice_out *host_tab = (venc_slice_out *)(slot + sizeof(venc_out_header));
         uint32_t byte_off = 0;
         for (int s = 0; s < g.n_slices; s++) {
-            const uint32_t nbits = s_bits[s], nbytes = (nbits + 1 + 7) >> 3;
+            const bool mine = s >= S.slice0 && s < S.slice1; /* slices of other bands: empty entries */
+            const uint32_t nbits = mine ? s_bits[s] : 0u, nbytes = mine ? (nbits + 1 + 7) >> 3 : 0u;
             const venc_slice_out so = {byte_off, nbytes, nbits, 0};
             slice_dev[(size_t)item * g.n_slices + s] = so;
             host_tab[s] = so;
@@ -930,7 +931,7 @@ DEVFN uint32_t fetch_bits(const uint32_t *wds, int pos, int n) { /* 1 <= n <= 32
  * the run sit in LDS; a word finds its first macroblock by binary search there. */
 __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_step S, const venc_slice_out *slice_dev) {
     __shared__ uint32_t s_off[PACK_MBS], s_nb[PACK_MBS];
-    const int item = blockIdx.z, s = blockIdx.y, tid = threadIdx.x;
+    const int item = blockIdx.z, s = S.slice0 + blockIdx.y, tid = threadIdx.x;
     const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
     const int m0 = first + blockIdx.x * PACK_MBS;
     if (m0 >= last) return;
@@ -988,5 +989,34 @@ __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_ste
             val = got ? (val << (32 - got)) : 0u;
         }
         out[w] = __builtin_bswap32(val);
+    }
+}
+
+/* ================================================================== k_band_copy
+ * Slice-parallel multi-GPU mode (BASELINE config 5): moves the rows of a
+ * band of the last reconstruction between the frame buffers and a contiguous exchange chunk
+ * (the unit handed to RCCL).  A band is whole MB rows, so each plane contributes one contiguous
+ * run of bytes (whole band) or two (the top and bottom halo rows only); the launcher describes
+ * them as up to six segments.  grid = (blocks, segment, item); 16 bytes per lane per trip. */
+typedef struct {
+    uint32_t frame_off, chunk_off, bytes; /* all multiples of 16 */
+} venc_band_seg;
+typedef struct {
+    int n_seg, to_chunk;
+    size_t item_stride; /* bytes between the chunks of consecutive items */
+    venc_band_seg seg[6];
+} venc_band_job;
+
+__global__ __launch_bounds__(256) void k_band_copy(venc_bufs B, int parity, venc_band_job J, uint8_t *chunk) {
+    const int item = blockIdx.z;
+    const venc_band_seg sg = J.seg[blockIdx.y];
+    uint4 *f = (uint4 *)(B.recon + (size_t)(parity * B.max_items + item) * B.recon_frame_bytes + sg.frame_off);
+    uint4 *c = (uint4 *)(chunk + (size_t)item * J.item_stride + sg.chunk_off);
+    const uint32_t n = sg.bytes >> 4;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        if (J.to_chunk)
+            c[i] = f[i];
+        else
+            f[i] = c[i];
     }
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     __shared__ __attribute__((aligned(4))) uint16_t s_rank[VENC_ME_CANDS + 1];
 
     const int item = blockIdx.z, tid = threadIdx.x;
-    const int x0 = blockIdx.x * T2_MBX * 16, y0 = blockIdx.y * T2_MBY * 16;
+    const int x0 = blockIdx.x * T2_MBX * 16, y0 = (S.row0 + blockIdx.y * T2_MBY) * 16;
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
@@ -82,8 +82,8 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
     const int hw = tid >> 5;
     const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
-    const int mx = blockIdx.x * T2_MBX + mbx, my = blockIdx.y * T2_MBY + mby;
-    const bool mb_valid = mx < g.mbw && my < g.mbh;
+    const int mx = blockIdx.x * T2_MBX + mbx, my = S.row0 + blockIdx.y * T2_MBY + mby;
+    const bool mb_valid = mx < g.mbw && my < S.row1;
     const int col0 = mbx * 16, row0 = mby * 16;
     /* this lane's 8 pixels of its macroblock (row l32/2, half l32&1): fetched now, used after the
      * block sums are built, so the load latency hides behind P0-P2 */

@@ -61,7 +61,15 @@ struct x264_t {
     h264_seq seq;
     int nal_cap;
     int external_input; /* venc_set_input is active (resident mode) */
+    int band_first, band_count; /* slices coded by this encoder (slice-parallel mode), 0/0 = all */
 };
+
+/* slice-parallel mode: let the bands' owners swap reconstructed rows before the next P picture */
+static int exchange_after_step(x264_t *h, int n_items) {
+    if (!h->band_count) return 0;
+    if (!h->param.hip.pf_exchange) return 0; /* a single band covering every slice needs no peer */
+    return h->param.hip.pf_exchange(h->param.hip.p_exchange_user, h->ctx, n_items) != 0 ? -1 : 0;
+}
 
 static double now_ms(void) {
     struct timespec ts;
@@ -191,6 +199,21 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     h->seq.sar_w = param->vui.i_sar_width;
     h->seq.sar_h = param->vui.i_sar_height;
     h->nal_cap = 2 + venc_n_slices(h->ctx);
+    if (param->hip.i_slice_count > 0 || param->hip.i_slice_first > 0) {
+        const int ns = venc_n_slices(h->ctx);
+        h->band_first = param->hip.i_slice_first;
+        h->band_count = param->hip.i_slice_count > 0 ? param->hip.i_slice_count : ns - param->hip.i_slice_first;
+        if (h->band_count < ns && !param->hip.pf_exchange) {
+            fprintf(stderr, "x264 [venc]: a slice band needs hip.pf_exchange (its P pictures read the other bands' rows)\n");
+            x264_encoder_close(h);
+            return NULL;
+        }
+        if (venc_set_band(h->ctx, h->band_first, h->band_count) != 0) {
+            fprintf(stderr, "x264 [venc]: %s\n", venc_last_error());
+            x264_encoder_close(h);
+            return NULL;
+        }
+    }
     if (!h->ring) {
         x264_encoder_close(h);
         return NULL;
@@ -235,6 +258,8 @@ static int launch_pending(x264_t *h, int flush) {
             if (fr->is_idr) h->gop_counter++;
             fr->ticket = venc_mark(h->ctx);
             if (fr->ticket < 0) return -1;
+            /* frame f+1, if it comes, is a P picture unless it opens a GOP (every band's owner decides alike) */
+            if ((f + 1) % h->keyint != 0 && exchange_after_step(h, 1) != 0) return -1;
         } else {
             const int gops = (n + h->keyint - 1) / h->keyint, rem = n % h->keyint;
             for (int t = 0; t < h->keyint && t < n; t++) {
@@ -253,6 +278,7 @@ static int launch_pending(x264_t *h, int flush) {
                 const int ticket = venc_mark(h->ctx);
                 if (ticket < 0) return -1;
                 for (int g = 0; g < items; g++) h->ring[(h->n_launched + (int64_t)g * h->keyint + t) % h->pool].ticket = ticket;
+                if (t + 1 < h->keyint && t + 1 < n && exchange_after_step(h, items) != 0) return -1;
             }
             h->gop_counter += gops;
         }
@@ -281,7 +307,7 @@ static int assemble_frame(x264_t *h, int64_t f) {
     size_t o = 0;
     int n = 0;
     const int annexb = h->param.b_annexb;
-    if (fr->is_idr) {
+    if (fr->is_idr && h->band_first == 0) {
         uint8_t rbsp[96];
         size_t k = h264_write_sps(&h->seq, rbsp, sizeof(rbsp));
         size_t sz = h264_wrap_nal(fr->payload + o, annexb, NAL_PRIORITY_HIGHEST, NAL_SPS, rbsp, k);
@@ -295,6 +321,7 @@ static int assemble_frame(x264_t *h, int64_t f) {
     const int ref_idc = fr->is_idr ? NAL_PRIORITY_HIGHEST : NAL_PRIORITY_HIGH;
     const int type = fr->is_idr ? NAL_SLICE_IDR : NAL_SLICE;
     for (uint32_t s = 0; s < vf.n_slices && n < h->nal_cap; s++) {
+        if (h->band_count && vf.slices[s].nbytes == 0) continue; /* another band's slice */
         const size_t sz = h264_wrap_nal(fr->payload + o, annexb, ref_idc, type, vf.data + vf.slices[s].byte_off, vf.slices[s].nbytes);
         fr->nals[n++] = (x264_nal_t){ref_idc, type, (int)sz, fr->payload + o};
         o += sz;
