@@ -16,6 +16,13 @@ encodes its own clip (independent streams / closed GOPs shard with no data-path
 collective -- SURVEY.md section 8e, BASELINE config 4); value = pixels of all
 ranks / max-over-ranks time; scaling = "weak".
 
+--mode slices (BASELINE config 5, e.g. --workload 2160p): ONE stream, every picture cut into the
+same 8 slices whatever N is, rank r codes a contiguous band of slices and the ranks swap
+reconstructed rows once per picture (RCCL all-gather on the engine's stream,
+video-encoder_amd/dist.py BandExchange); the bands' payloads are gathered on rank 0 and
+interleaved into the single-encoder bitstream inside the timed region; value = pixels of the
+one clip / max-over-ranks time; scaling = "strong".
+
 Extra objects in the JSON line:
   roofline      dominant kernel (k_me) against the HBM-read roofline, from HIP
                 events recorded on the engine's stream inside the timed region
@@ -75,6 +82,9 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--mode", default="streams", choices=("streams", "slices"),
+                    help="streams: one clip per GPU, no collective (default); slices: one clip, slice bands across GPUs")
+    ap.add_argument("--halo", type=int, default=16, help="slices mode: luma rows exchanged per band edge (0 = whole bands)")
     ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -104,12 +114,19 @@ def main():
 
     # synthetic clip, generated on the GPU straight into HBM (same bytes as the host generator)
     clip = torch.empty(frames * fb, dtype=torch.uint8, device="cuda")
-    if venc.hip_lib().venc_synth_device(clip.data_ptr(), fb, w, h, 0, frames, 0x1234ABCD + rank) != 0:
+    slices_mode = args.mode == "slices"
+    if venc.hip_lib().venc_synth_device(clip.data_ptr(), fb, w, h, 0, frames, 0x1234ABCD + (0 if slices_mode else rank)) != 0:
         raise SystemExit("venc_synth_device failed")
     torch.cuda.synchronize()
 
+    band_kw, xc, dmod = {}, None, None
+    if slices_mode:
+        dmod = importlib.import_module("video-encoder_amd.dist")
+        s0, cnt = dmod.slice_band(wl["slices"], world, rank)
+        xc = dmod.BandExchange(dmod.EnginePort(local_rank), wl["slices"], world, rank, halo_rows=args.halo)
+        band_kw = dict(slice_first=s0, slice_count=cnt, exchange=xc)
     enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
-                           gop_batch=gop_batch, device=local_rank)
+                           gop_batch=gop_batch, device=local_rank, **band_kw)
     if not args.no_profile:
         enc.profile(True, capacity=8 * frames * max(1, args.steps))
 
@@ -118,15 +135,30 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    stream_info = {}
+
+    def one_pass():
+        """streams: C tally sink.  slices: collect this band's payloads, gather them on rank 0 and
+        interleave them into the whole-picture bitstream (part of the job, so inside the timing)."""
+        if not slices_mode:
+            return enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+        mine = []
+        enc.encode_resident(clip.data_ptr(), fb, frames, sink=lambda payload, nals, pts, key: mine.append(payload))
+        parts = dmod.gather_frames(mine)
+        if rank == 0:
+            whole = dmod.interleave_bands(parts)
+            stream_info["frames"] = whole
+        return None
+
     tally = None
     for _ in range(args.warmup):
-        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+        tally = one_pass()
     if not args.no_profile:
         enc.profile_read()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+        tally = one_pass()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
@@ -136,10 +168,11 @@ def main():
     # chain's kernels takes longer although it does the same work).
     prof_iso = {}
     if not args.no_profile and rank == 0:
-        enc.set_overlap(False)
-        enc.encode_resident_tally(clip.data_ptr(), fb, frames)
-        prof_iso, _ = enc.profile_read()
-        enc.set_overlap(True)
+        if not slices_mode:  # (every rank would have to join the exchanges of an extra pass)
+            enc.set_overlap(False)
+            enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+            prof_iso, _ = enc.profile_read()
+            enc.set_overlap(True)
     barrier()
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
@@ -147,7 +180,7 @@ def main():
         dt = float(tt.item())
 
     if rank == 0:
-        px = world * args.steps * frames * w * h
+        px = (1 if slices_mode else world) * args.steps * frames * w * h
         out = {
             "metric": "Mpixels/s encoded at fixed QP, 1080p & 4K YUV420p; bit-exact vs CPU ref",
             "value": round(px / dt / 1e6, 2),
@@ -157,22 +190,34 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if slices_mode else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": wl["name"], "frames_per_step": frames, "gop_batch": gop_batch,
-                       "parallelism": "1 stream per GPU, no collective" if world > 1 else "single GPU",
+                       "parallelism": ("%d slice bands of one stream, %s exchange of reconstructed rows per picture (%s)" % (
+                           world, "halo (%d luma rows per edge)" % args.halo if args.halo else "whole-band", args.backend))
+                       if slices_mode else ("1 stream per GPU, no collective" if world > 1 else "single GPU"),
                        "bytes_per_step": int(tally.bytes) if tally else None,
                        "bitstream_fnv1a": "%016x" % tally.fnv1a if tally else None,
                        "cpu_oracle_note": "bit-exact vs this repo's CPU oracle (tests/); parity with libx264 unpinned"},
         }
+        if slices_mode:
+            import hashlib
+            whole = stream_info.get("frames", [])
+            out["config"]["bytes_per_step"] = sum(len(f) for f in whole)
+            out["config"]["bitstream_sha256"] = hashlib.sha256(b"".join(whole)).hexdigest()
+            out["config"]["exchanges_per_step"] = xc.exchanges // max(1, args.steps + args.warmup)
+            out["config"].pop("bitstream_fnv1a", None)
         if prof:
             me_ms, me_n = prof.get("k_me", (0.0, 0))
             total_ms = sum(v[0] for v in prof.values())
             if me_n:
                 launches_per_step = me_n / args.steps
                 px_per_launch = (frames - (frames + keyint - 1) // keyint) * w * h / launches_per_step
+                if slices_mode:  # rank 0 searches only its band
+                    r0, r1 = venc.Engine.view(enc.L.x264_venc_engine(enc.h)).band_rows(*dmod.slice_band(wl["slices"], world, 0))
+                    px_per_launch *= (r1 - r0) * 16.0 / h
                 algo_bytes = ME_ALGO_BYTES_PER_PX * px_per_launch
                 avg_s = me_ms / me_n * 1e-3
                 achieved = algo_bytes / avg_s / 1e9
