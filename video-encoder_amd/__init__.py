@@ -152,6 +152,7 @@ def hip_lib():
         L.venc_profile_name.restype = C.c_char_p
         L.venc_profile_name.argtypes = [C.c_int]
         L.venc_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.venc_profile_select.argtypes = [C.c_void_p, C.c_uint]
         L.venc_set_band.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.venc_band_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.venc_band_chunk_bytes.restype = C.c_size_t
@@ -461,6 +462,18 @@ class X264Encoder:
     def profile(self, enable=True, capacity=8192):
         if hip_lib().venc_profile(self.L.x264_venc_engine(self.h), int(enable), capacity) != 0:
             raise VencError("venc_profile failed")
+
+    def profile_select(self, names=None):
+        """Event pairs only around the named kernels (None = all): each pair costs the stream a few microseconds."""
+        H = hip_lib()
+        mask = 0xffffffff
+        if names is not None:
+            all_names = [H.venc_profile_name(i).decode() for i in range(H.venc_profile_kernels())]
+            mask = 0
+            for n in names:
+                mask |= 1 << all_names.index(n)
+        if H.venc_profile_select(self.L.x264_venc_engine(self.h), mask) != 0:
+            raise VencError("venc_profile_select failed")
 
     def set_overlap(self, enable):
         if hip_lib().venc_set_overlap(self.L.x264_venc_engine(self.h), int(bool(enable))) != 0:

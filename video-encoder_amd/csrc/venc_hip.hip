@@ -61,27 +61,32 @@ struct venc_ctx {
     int steps_done;
     int band_s0, band_s1; /* slices coded by this context (venc_set_band); whole picture by default */
     int slice_rows[VENC_MAX_SLICES + 1];
+    int me_stop;
     int cavlc_legacy; /* VENC_CAVLC=legacy: half-wave-per-macroblock k_cavlc for P pictures too */
     int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
     int me_mode;  /* 0 tile (default): successive elimination, sums built in-kernel; 1 plane: sums from k_refsum;
                      2 dense: exhaustive search.  Env VENC_ME=tile|plane|dense (VENC_ME_DENSE=1 = dense). */
     /* optional per-kernel HIP-event timing (venc_profile) */
     int prof_on;
+    unsigned prof_mask; /* kernels that get event pairs (bit = kernel id); every pair costs the stream a few microseconds */
     hipEvent_t *prof_ev; /* pairs */
     int *prof_kid;
-    int prof_n, prof_cap;
+    int prof_n, prof_cap, prof_open;
 };
 
 enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_COUNT };
 static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma"};
 
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
-    if (!c->prof_on || c->prof_n >= c->prof_cap) return;
+    c->prof_open = 0;
+    if (!c->prof_on || !((c->prof_mask >> kid) & 1u) || c->prof_n >= c->prof_cap) return;
+    c->prof_open = 1;
     c->prof_kid[c->prof_n] = kid;
     (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
 }
 static void prof_end(venc_ctx *c, hipStream_t st) {
-    if (!c->prof_on || c->prof_n >= c->prof_cap) return;
+    if (!c->prof_open) return;
+    c->prof_open = 0;
     (void)hipEventRecord(c->prof_ev[2 * c->prof_n + 1], st);
     c->prof_n++;
 }
@@ -296,6 +301,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (m && !strcmp(m, "dense")) c->me_mode = 2;
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
+    c->me_stop = getenv("VENC_ME_STOP") ? atoi(getenv("VENC_ME_STOP")) : 0;
     c->cavlc_legacy = getenv("VENC_CAVLC") && !strcmp(getenv("VENC_CAVLC"), "legacy");
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
@@ -421,6 +427,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.is_idr = is_idr ? 1 : 0;
     S.frame_num = frame_num;
     S.parity = c->parity;
+    S.me_stop = c->me_stop;
     S.slice0 = c->band_s0;
     S.slice1 = c->band_s1;
     S.row0 = c->slice_rows[c->band_s0];
@@ -452,7 +459,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
         prof_end(c, s1);
     } else {
-        if (c->me_mode == 0) HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
+        /* fix_count is zero at open and re-zeroed by k_inter_luma once k_me_fix has consumed it; only the
+         * legacy transform kernel needs the memset node */
+        if (c->me_mode == 0 && c->inter_legacy) HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
         if (c->me_mode == 2)
             hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, band_rows, n_items), dim3(256), 0, s1, g, b, S);
@@ -725,7 +734,13 @@ extern "C" int venc_profile(venc_ctx *c, int enable, int capacity) {
         for (int i = 0; i < 2 * c->prof_cap; i++) HIP_OK(hipEventCreate(&c->prof_ev[i]));
     }
     c->prof_on = enable ? 1 : 0;
+    c->prof_mask = 0xffffffffu;
     c->prof_n = 0;
+    return 0;
+}
+
+extern "C" int venc_profile_select(venc_ctx *c, unsigned kernel_mask) {
+    c->prof_mask = kernel_mask;
     return 0;
 }
 extern "C" int venc_profile_kernels(void) { return KID_COUNT; }

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     if (tid + 512 < 545) ((uint32_t *)s_rank)[tid + 512] = rk1;
     __syncthreads();
     ME_STAMP(0);
+    if (S.me_stop == 1) return;
     /* ---- P1: horizontal 8-sums, four columns per item ---- */
     {   /* thread = (row, run of 5 column groups): 6 sliding-sum instructions give 5 groups of 8-sums */
         const int r = tid >> 3, q0 = (tid & 7) * 5;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     }
     __syncthreads();
     ME_STAMP(1);
+    if (S.me_stop == 2) return;
     /* ---- P2: vertical 8-sums, stored as vertical pairs V(x,y) = S8(x,y) | S8(x,y+8) << 16 so that the
      * bound of a candidate needs two dword reads (left and right 8x8 columns) and no repacking.
      * 7 segments of 8 rows x 39 column groups; a thread slides down 16 rows of block sums. */
@@ -192,6 +194,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     }
     __syncthreads();
     ME_STAMP(2);
+    if (S.me_stop == 3) return;
     /* ---- per macroblock: one half-wave ---- */
     ME_STAMP(3);
     uint32_t part = __builtin_amdgcn_sad_u8(c0, 0u, 0u);
@@ -229,6 +232,10 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
 #pragma unroll
     for (int cy = 0; cy < 33; cy++) lmin = min(lmin, (lb[cy] << 12) | (uint32_t)(cy * 33 + l32));
     const int ai = (int)(half_min32(lmin, lane) & 4095u);
+    if (S.me_stop == 4) {
+        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = (uint32_t)ai << 16;
+        return;
+    }
     const int acy = ai / 33, acx = ai - acy * 33;
     const uint32_t sad_z = me2_coop_sad(s_win, col0, row0, lane, c0, c1, 16, 16);
     const uint32_t sad_p = me2_coop_sad(s_win, col0, row0, lane, c0, c1, pcx, pcy);
@@ -254,6 +261,10 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     }
     ME_STAMP(5);
     __syncthreads();
+    if (S.me_stop == 5) {
+        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = best << 16;
+        return;
+    }
     const uint32_t cnt = s_cnt[hw];
     const bool overflow = cnt > SEA_LIST;
     const uint32_t cnt_eff = overflow ? 0u : cnt;
