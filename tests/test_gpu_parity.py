@@ -205,7 +205,8 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
         yy, xx = np.mgrid[0:h, 0:w]
         frames = [((((xx + 2 * t) // 4) % 2) * 200 + 20).astype(np.uint8) for t in range(n)]
         frames = [(f, np.full((h // 2, w // 2), 128, np.uint8), np.full((h // 2, w // 2), 128, np.uint8)) for f in frames]
-    a = _me_run(venc, frames, w, h, "tile")      # default: sums built in-kernel + k_me_fix
+    a = _me_run(venc, frames, w, h, "pool")      # default: k_me_pool (persistent blocks, pooled survivors) + k_me_fix
+    d = _me_run(venc, frames, w, h, "tile")      # its predecessor k_me_tile
     b = _me_run(venc, frames, w, h, "dense")     # exhaustive
     c = _me_run(venc, frames, w, h, "plane")     # sums from the k_refsum plane, in-kernel dense fallback
     enc = orc.Encoder(w, h, qp=26, n_slices=4, keyint=100, threads=8)
@@ -213,7 +214,8 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
         enc.encode(y, u, v)
         assert np.array_equal(a[t][0], b[t][0]), "%s frame %d: pruned (tile) != exhaustive" % (kind, t)
         assert np.array_equal(c[t][0], b[t][0]), "%s frame %d: pruned (plane) != exhaustive" % (kind, t)
-        assert a[t][1] == b[t][1] and c[t][1] == b[t][1]
+        assert np.array_equal(d[t][0], b[t][0]), "%s frame %d: pruned (k_me_tile) != exhaustive" % (kind, t)
+        assert a[t][1] == b[t][1] and c[t][1] == b[t][1] and d[t][1] == b[t][1]
         if t:
             mv = np.stack([(a[t][0] & 0xff).astype(np.int8), ((a[t][0] >> 8) & 0xff).astype(np.int8)], axis=1)
             assert np.array_equal(mv, enc.mv()), "%s frame %d: mv != oracle" % (kind, t)
