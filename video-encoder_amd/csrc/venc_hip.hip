@@ -63,11 +63,10 @@ struct venc_ctx {
     int band_s0, band_s1; /* slices coded by this context (venc_set_band); whole picture by default */
     int slice_rows[VENC_MAX_SLICES + 1];
     int me_stop;
-    int me_blocks; /* persistent blocks of k_me_pool: 2 per CU */
     int cavlc_legacy; /* VENC_CAVLC=legacy: half-wave-per-macroblock k_cavlc for P pictures too */
     int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
-    int me_mode;  /* 0 pool (default): k_me_pool, successive elimination with in-kernel sums, persistent blocks, pooled
-                     survivors; 3 tile: its predecessor k_me_tile; 1 plane: sums from k_refsum; 2 dense: exhaustive
+    int me_mode;  /* 0 pool (default): k_me_pool, successive elimination with in-kernel sums, pooled survivors, three
+                     blocks per CU; 3 tile: its predecessor k_me_tile; 1 plane: sums from k_refsum; 2 dense: exhaustive
                      search.  Env VENC_ME=pool|tile|plane|dense (VENC_ME_DENSE=1 = dense). */
     /* optional per-kernel HIP-event timing (venc_profile) */
     int prof_on;
@@ -145,7 +144,6 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.stamps);
     (void)hipFree(c->b.fix_count);
     (void)hipFree(c->b.fix_list);
-    (void)hipFree(c->b.me_ctr);
     (void)hipFree(c->d_slice);
     (void)hipFree(c->d_slice_rows);
     (void)hipFree(c->d_row_slice);
@@ -306,13 +304,6 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (m && !strcmp(m, "tile")) c->me_mode = 3;
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
-    {
-        hipDeviceProp_t prop;
-        OPEN_OK(hipGetDeviceProperties(&prop, cfg->device));
-        (void)prop;
-        c->me_blocks = 0; /* measured: one tile per block beats persistent blocks once the entropy chain runs beside it */
-        if (getenv("VENC_ME_BLOCKS")) c->me_blocks = atoi(getenv("VENC_ME_BLOCKS")); /* 0: one tile per block, no persistence */
-    }
     c->me_stop = getenv("VENC_ME_STOP") ? atoi(getenv("VENC_ME_STOP")) : 0;
     c->cavlc_legacy = getenv("VENC_CAVLC") && !strcmp(getenv("VENC_CAVLC"), "legacy");
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
@@ -321,8 +312,6 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.fix_count, G * 4));
     OPEN_OK(hipMemset(b.fix_count, 0, G * 4));
     OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
-    OPEN_OK(hipMalloc(&b.me_ctr, 8 * 32 * 4)); /* one head per 128-byte line (ME3_CTR_STRIDE) */
-    OPEN_OK(hipMemset(b.me_ctr, 0, 8 * 32 * 4));
     OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMalloc(&b.me_cnt, G * nmb));
@@ -475,10 +464,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     } else {
         /* fix_count is zero at open and re-zeroed by k_inter_luma once k_me_fix has consumed it; only the
          * legacy transform kernel needs the memset node */
-        if ((c->me_mode == 0 || c->me_mode == 3) && c->inter_legacy) {
-            HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
-            HIP_OK(hipMemsetAsync(c->b.me_ctr, 0, 8 * 32 * 4, s1));
-        }
+        if ((c->me_mode == 0 || c->me_mode == 3) && c->inter_legacy) HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
         if (c->me_mode == 2)
             hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, band_rows, n_items), dim3(256), 0, s1, g, b, S);
@@ -487,18 +473,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         else if (c->me_mode == 3)
             hipLaunchKernelGGL(k_me_tile, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
                                s1, g, b, S);
-        else {
-            /* persistent blocks: two per CU (LDS-limited), a multiple of 8 so that blocks b, b+8, ... split the tiles evenly */
-            const int tiles_x = (g.mbw + T2_MBX - 1) / T2_MBX, tiles_y = (band_rows + T2_MBY - 1) / T2_MBY;
-            const int n_tiles = tiles_x * tiles_y * n_items;
-            if (c->me_blocks > 0) {
-                int blocks = n_tiles < c->me_blocks ? n_tiles : c->me_blocks;
-                blocks = (blocks + 7) & ~7;
-                hipLaunchKernelGGL(k_me_pool<true>, dim3(blocks), dim3(512), 0, s1, g, b, S, tiles_x, tiles_y, n_tiles);
-            } else {
-                hipLaunchKernelGGL(k_me_pool<false>, dim3(n_tiles), dim3(512), 0, s1, g, b, S, tiles_x, tiles_y, n_tiles);
-            }
-        }
+        else
+            hipLaunchKernelGGL(k_me_pool, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
+                               s1, g, b, S);
         prof_end(c, s1);
         if (c->me_mode == 0 || c->me_mode == 3) {
             prof_begin(c, KID_MEFIX, s1);

@@ -70,7 +70,6 @@ __global__ __launch_bounds__(256) void k_inter_luma(venc_geom g, venc_bufs B, ve
     const int lane = tid & 63, blk = lane & 15, gbase = lane & 48;
     const int mb_raw = S.mb0 + blockIdx.x * 16 + (tid >> 4);
     if (blockIdx.x == 0 && tid == 0) B.fix_count[item] = 0; /* consumed by k_me_fix; ready for the next step's motion search */
-    if (blockIdx.x == 0 && item == 0 && tid < 8) B.me_ctr[tid * 32] = 0; /* tile queues of k_me_pool */
     const bool valid = mb_raw < S.mb1;
     const int mb = valid ? mb_raw : S.mb1 - 1;
     const int mx = mb % g.mbw, my = mb / g.mbw;

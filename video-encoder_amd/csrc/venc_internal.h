@@ -96,7 +96,6 @@ typedef struct {
     uint8_t *me_flag;           /* [G][nmb] 1 = k_me_tile left this macroblock to k_me_fix */
     uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zeroed before k_me_tile) */
     uint32_t *fix_list;         /* [G][nmb] their indices */
-    uint32_t *me_ctr;           /* [8] tile queue heads of k_me_pool (zero at open, re-zeroed by k_inter_luma) */
     unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
     uint8_t *out_base;          /* device view of the pinned output pool */
