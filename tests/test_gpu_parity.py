@@ -263,7 +263,7 @@ def test_legacy_and_split_inter_kernels_agree(venc):
             eng.upload(t % 2, y, u, v)
             eng.encode_step([t % 2], [t % 2], t == 0, t & 15, [0])
             eng.sync()
-            res.append((eng.debug(1), eng.debug(2)[:, :26], eng.debug(4), eng.debug(5), eng.debug(6), eng.get_slices(t % 2)))
+            res.append((eng.debug(1), eng.debug(2)[:, :27], eng.debug(4), eng.debug(5), eng.debug(6), eng.get_slices(t % 2)))
         eng.close()
         outs.append(res)
     for t in range(n):

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
     __syncthreads();
     if (!valid) return;
 
-    const int cbp = (int)(o1.z & 255u), cbpl = cbp & 15, cbpc = cbp >> 4;
+    const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
     uint32_t *strip = s_lv + tid * 9;
     const int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
     venc_bitsink bs;

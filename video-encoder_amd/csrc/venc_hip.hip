@@ -77,6 +77,7 @@ struct venc_ctx {
 };
 
 enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_COUNT };
+/* "k_inter" = k_inter_fused (luma + chroma transforms) */
 static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma"};
 
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
@@ -462,9 +463,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
         prof_end(c, s1);
     } else {
-        /* fix_count is zero at open and re-zeroed by k_inter_luma once k_me_fix has consumed it; only the
-         * legacy transform kernel needs the memset node */
-        if ((c->me_mode == 0 || c->me_mode == 3) && c->inter_legacy) HIP_OK(hipMemsetAsync(c->b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
+        /* fix_count is zero here: zeroed at open and by k_inter_fused once k_me_fix has consumed it; the legacy
+         * transform kernel does not do that and takes a memset node instead */
+        if (c->inter_legacy) HIP_OK(hipMemsetAsync(b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
         if (c->me_mode == 2)
             hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, band_rows, n_items), dim3(256), 0, s1, g, b, S);
@@ -477,7 +478,8 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_me_pool, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
                                s1, g, b, S);
         prof_end(c, s1);
-        if (c->me_mode == 0 || c->me_mode == 3) {
+        const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */
+        if (flags_mbs) {
             prof_begin(c, KID_MEFIX, s1);
             hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
@@ -487,11 +489,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_inter, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
         } else {
+            /* luma transform and chroma transform: independent blocks of one launch */
+            const int n_luma = (band_mbs + 15) / 16, n_chroma = (band_mbs + 31) / 32;
             prof_begin(c, KID_INTER, s1);
-            hipLaunchKernelGGL(k_inter_luma, dim3((band_mbs + 15) / 16, 1, n_items), dim3(256), 0, s1, g, b, S);
-            prof_end(c, s1);
-            prof_begin(c, KID_INTER_C, s1);
-            hipLaunchKernelGGL(k_inter_chroma, dim3((band_mbs + 31) / 32, 1, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, b, S, n_luma);
             prof_end(c, s1);
         }
     }
@@ -714,7 +715,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         static const int blk_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
         for (size_t m = 0; m < nmb; m++) {
             int16_t *r = lv + m * VENC_MB_COEFS;
-            const int i16 = mi[m].flags & 1, cbpc = mi[m].cbp >> 4;
+            const int i16 = mi[m].flags & 1, cbpc = mi[m].cbpc;
             for (int b = 0; b < 16; b++)
                 if (mi[m].nnz[blk_raster[b]] == 0) memset(r + b * 16, 0, 32);
             if (!i16) memset(r + 16 * 16, 0, 32);

@@ -5,11 +5,11 @@
  * The first version (k_inter in venc_kernels.hip) gave one half-wave to each macroblock: 16 luma
  * lanes, 8 chroma lanes, 8 idle, and the luma and chroma prediction paths ran one after the
  * other under divergence -- ~415 wave instructions per macroblock.  Here luma and chroma are
- * separate launches with homogeneous waves:
- *   k_inter_luma    16 lanes per macroblock, 4 macroblocks per wave   (lane = luma4x4BlkIdx)
- *   k_inter_chroma   8 lanes per macroblock, 8 macroblocks per wave   (lane = plane*4 + block)
- * Quantiser constants are wave-uniform (SGPRs), no per-lane selects.  k_inter_luma writes the
- * luma half of coded_block_pattern, k_inter_chroma (next on the stream) ORs in the chroma half.
+ * separate blocks of one launch (k_inter_fused) with homogeneous waves:
+ *   luma blocks     16 lanes per macroblock, 4 macroblocks per wave   (lane = luma4x4BlkIdx)
+ *   chroma blocks    8 lanes per macroblock, 8 macroblocks per wave   (lane = plane*4 + block)
+ * Quantiser constants are wave-uniform (SGPRs), no per-lane selects.  The luma and chroma halves of
+ * coded_block_pattern go to separate bytes of the macroblock record (they are written concurrently).
  */
 
 template <bool DC_SEP>
@@ -65,18 +65,12 @@ DEVFN void load_cur4x4(const uint8_t *cur, int cstride, int pw, int ph, int px, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_inter_luma(venc_geom g, venc_bufs B, venc_step S) {
-    const int item = blockIdx.z, tid = threadIdx.x;
-    const int lane = tid & 63, blk = lane & 15, gbase = lane & 48;
-    const int mb_raw = S.mb0 + blockIdx.x * 16 + (tid >> 4);
-    if (blockIdx.x == 0 && tid == 0) B.fix_count[item] = 0; /* consumed by k_me_fix; ready for the next step's motion search */
-    const bool valid = mb_raw < S.mb1;
-    const int mb = valid ? mb_raw : S.mb1 - 1;
+/* luma transform of macroblock mb with vector (dx, dy): 16 lanes, lane & 15 = luma4x4BlkIdx, lane & 48 = the
+ * wave's group of 16; every lane of the wave calls this (ballots), `valid` guards the stores */
+DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy) {
+    const int blk = lane & 15, gbase = lane & 48;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
-    const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
-    const int dx = (int)(int8_t)(mvs & 255u), dy = (int)(int8_t)((mvs >> 8) & 255u);
-
     int cstride, pw, ph, rstride, wstride;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
@@ -119,23 +113,17 @@ __global__ __launch_bounds__(256) void k_inter_luma(venc_geom g, venc_bufs B, ve
 #pragma unroll
             for (int qd = 0; qd < 4; qd++)
                 if ((h >> (4 * qd)) & 15u) cbpl |= 1 << qd;
-            info->cbp = (uint8_t)cbpl; /* k_inter_chroma adds the chroma bits */
+            info->cbp = (uint8_t)cbpl; /* the chroma part has its own byte (cbpc) */
             info->flags = 0;
         }
     }
 }
 
-__global__ __launch_bounds__(256) void k_inter_chroma(venc_geom g, venc_bufs B, venc_step S) {
-    const int item = blockIdx.z, tid = threadIdx.x;
-    const int lane = tid & 63, k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
-    const int mb_raw = S.mb0 + blockIdx.x * 32 + (tid >> 3);
-    const bool valid = mb_raw < S.mb1;
-    const int mb = valid ? mb_raw : S.mb1 - 1;
+/* chroma transform of macroblock mb: 8 lanes, lane & 3 = block, (lane >> 2) & 1 = plane, lane & 56 = group of 8 */
+DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy) {
+    const int k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
-    const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
-    const int dx = (int)(int8_t)(mvs & 255u), dy = (int)(int8_t)((mvs >> 8) & 255u);
-
     int cstride, pw, ph, rstride, wstride;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, plane, rstride);
@@ -206,8 +194,36 @@ __global__ __launch_bounds__(256) void k_inter_chroma(venc_geom g, venc_bufs B, 
         }
         if ((lane & 7) == 0) {
             const uint32_t hac = (uint32_t)(bal_ac >> gbase) & 0xffu, hdc = (uint32_t)(bal_dc >> gbase) & 0xffu;
-            const int cbpc = hac ? 2 : hdc ? 1 : 0;
-            info->cbp = (uint8_t)((info->cbp & 15) | (cbpc << 4));
+            info->cbpc = (uint8_t)(hac ? 2 : hdc ? 1 : 0);
         }
+    }
+}
+
+/* ================================================================== k_inter_fused
+ * The luma and the chroma transform of a P step as independent blocks of ONE launch (two back-to-back
+ * kernels cost a ramp-down and a ramp-up, and the chroma blocks need nothing from the luma blocks):
+ * the first n_luma blocks take 16 macroblocks each (luma), the rest 32 macroblocks each (chroma).
+ *
+ * Tried and dropped: a third kind of block in this launch that searched the flagged macroblocks
+ * exhaustively and transformed them, to hide k_me_fix's serial 13 us.  The search's registers
+ * (or, capped, its spills in the shared prologue) cost the transform blocks more occupancy than
+ * the hidden kernel was worth (74 us against 13 + 44 us). */
+__global__ __launch_bounds__(256) void k_inter_fused(venc_geom g, venc_bufs B, venc_step S, int n_luma) {
+    const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
+    const int bx = blockIdx.x;
+    const uint32_t *mvs = B.mvsad + (size_t)item * g.nmb;
+    if (bx >= n_luma) {
+        const int mb_raw = S.mb0 + (bx - n_luma) * 32 + (tid >> 3);
+        const bool valid = mb_raw < S.mb1;
+        const int mb = valid ? mb_raw : S.mb1 - 1;
+        const uint32_t m = mvs[mb];
+        inter_chroma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u));
+    } else {
+        if (bx == 0 && tid == 0) B.fix_count[item] = 0; /* consumed by k_me_fix; ready for the next step's motion search */
+        const int mb_raw = S.mb0 + bx * 16 + (tid >> 4);
+        const bool valid = mb_raw < S.mb1;
+        const int mb = valid ? mb_raw : S.mb1 - 1;
+        const uint32_t m = mvs[mb];
+        inter_luma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u));
     }
 }

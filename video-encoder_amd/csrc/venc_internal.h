@@ -29,9 +29,11 @@
 
 typedef struct {
     uint8_t nnz[24];
-    uint8_t cbp;   /* bits 0-3 luma 8x8, bits 4-5 chroma (0,1,2) */
+    uint8_t cbp;   /* coded_block_pattern, luma part: bits 0-3 = the four 8x8 blocks */
     uint8_t flags; /* bit 0: Intra16x16 */
-    uint8_t pad[6];
+    uint8_t cbpc;  /* coded_block_pattern, chroma part (0, 1, 2): its own byte, the luma and chroma transform
+                      blocks of a step run side by side and must not share one */
+    uint8_t pad[5];
 } venc_mbinfo;
 
 typedef struct {
@@ -94,7 +96,7 @@ typedef struct {
     int refsum_stride;          /* dwords per row */
     size_t refsum_item;         /* dwords per item */
     uint8_t *me_flag;           /* [G][nmb] 1 = k_me_tile left this macroblock to k_me_fix */
-    uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zeroed before k_me_tile) */
+    uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zero at open; re-zeroed by k_inter_fused after k_me_fix) */
     uint32_t *fix_list;         /* [G][nmb] their indices */
     unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */

@@ -486,7 +486,8 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
         for (int qd = 0; qd < 4; qd++)
             if ((hnz >> (4 * qd)) & 15u) cbpl |= 1 << qd;
         int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
-        info->cbp = (uint8_t)((cbpc << 4) | cbpl);
+        info->cbp = (uint8_t)cbpl;
+        info->cbpc = (uint8_t)cbpc;
         info->flags = 0;
     }
 }
@@ -612,7 +613,8 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                 if (lane == 0) {
                     int cbpl = (hnz & 0xffffu) ? 15 : 0;
                     int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
-                    info->cbp = (uint8_t)((cbpc << 4) | cbpl);
+                    info->cbp = (uint8_t)cbpl;
+                    info->cbpc = (uint8_t)cbpc;
                     info->flags = 1;
                     B.mvsad[(size_t)item * g.nmb + mb] = 0;
                 }
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     for (int k = 0; k < 3; k++)
         if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
     __syncthreads();
-    const int cbp = (int)(o1.z & 255u), cbpl = cbp & 15, cbpc = cbp >> 4;
+    const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
     const bool i16 = (o1.z >> 8) & 1u;
 
     /* role decode */

@@ -27,13 +27,17 @@
  *     from (all reads, a barrier, all writes): 51 KB of LDS per block instead of 68, and the register
  *     budget is held at 84, so six waves per SIMD hide the LDS and DPP latencies that four left bare.
  *
- * Tried and dropped (measured, same clip): persistent blocks pulling tiles from per-XCD queues with a
+ * Tried and dropped (measured, same clip): (a) searching the macroblocks with too many survivors exhaustively
+ * at the end of their own block, from the window already in LDS, instead of listing them for k_me_fix: such
+ * macroblocks cluster, a tile with 16 of them became a 40 us straggler and the launch grew from 83 to 109 us;
+ * (b) persistent blocks pulling tiles from per-XCD queues with a
  * register prefetch of the next tile.  Alone it was on par (96 us); beside the entropy chain that
  * runs on a second stream it lost 7 % of the whole step, because blocks that never retire keep the
  * other chain's blocks off the CUs they hold.
  */
 
-#define T3_POOL (T2_MBX * T2_MBY * SEA_LIST) /* 1024 entries: (LB << 15) | (macroblock << 11) | candidate */
+#define T3_POOL 1024 /* survivor pool of a tile; entry = (LB << 15) | (macroblock << 11) | candidate */
+#define T3_CAP SEA_LIST /* survivors one macroblock may put into the pool (64); more: exhaustive search by k_me_fix */
 #define T3_CW 32                             /* current tile row stride in dwords: 128 pixels */
 
 /* window piece i (row i / 10, columns 16 * (i % 10) ...): 16 bytes from the clamped address; a piece outside the
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     /* ---- survivors: bound <= best start SAD, appended to the tile's pool.  Compaction by wave ballots: a row of
      * bounds rarely holds a survivor, so the common case is one compare and one scalar branch per row; a row with
-     * survivors costs the wave one LDS atomic.  A macroblock with more than SEA_LIST survivors goes to k_me_fix. ---- */
+     * survivors costs the wave one LDS atomic.  A macroblock with more than T3_CAP survivors (or one that meets a full pool) is listed for the exhaustive search. ---- */
     uint32_t mycnt = 0; /* survivors of this lane's macroblock besides the start points */
     {
         const int thrk = mb_valid ? (int)((thr << 6) | 63u) : -1; /* (pk < 2^22: the signed compare never passes -1) */
@@ -296,18 +300,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 const uint32_t ci = (pv & 63u) * 33u + (uint32_t)l32;
                 const bool keep = hit && ci != (uint32_t)ci_p && ci != (uint32_t)ai;
                 const uint32_t hm = (uint32_t)(__ballot(keep) >> hbase);
-                const bool put = keep && mycnt + (uint32_t)__popc(hm & lt) < SEA_LIST;
+                const bool put = keep && mycnt + (uint32_t)__popc(hm & lt) < T3_CAP;
                 const unsigned long long pb = __ballot(put);
+                mycnt += (uint32_t)__popc(hm);
                 if (pb != 0ull) {
                     const int first = (int)__builtin_ctzll(pb);
                     uint32_t base = 0;
                     if (lane == first) base = atomicAdd(&s_total, (uint32_t)__popcll(pb));
                     base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-                    if (put)
-                        s_pool[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] =
-                            ((pv >> 6) << 15) | tag | ci;
+                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
+                    if (put && idx < T3_POOL) s_pool[idx] = ((pv >> 6) << 15) | tag | ci;
+                    if ((uint32_t)(__ballot(put && idx >= T3_POOL) >> hbase) != 0u) mycnt = T3_CAP + 1; /* pool full */
                 }
-                mycnt += (uint32_t)__popc(hm);
             }
         }
         {   /* column cx = 32 */
@@ -319,13 +323,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 const uint32_t hm0 = (uint32_t)(__ballot(k0) >> hbase), hm1 = (uint32_t)(__ballot(k1) >> hbase);
                 const uint32_t pos0 = mycnt + (uint32_t)__popc(hm0 & lt);
                 mycnt += (uint32_t)__popc(hm0);
-                const bool put0 = k0 && pos0 < SEA_LIST, put1 = k1 && mycnt < SEA_LIST;
+                const bool put0 = k0 && pos0 < T3_CAP, put1 = k1 && mycnt < T3_CAP;
                 mycnt += (uint32_t)__popc(hm1);
-                if (put0) s_pool[atomicAdd(&s_total, 1u)] = (lbx0 << 15) | tag | ci0;
-                if (put1) s_pool[atomicAdd(&s_total, 1u)] = (lbx1 << 15) | tag | ci1;
+                uint32_t i0 = 0, i1 = 0;
+                if (put0) i0 = atomicAdd(&s_total, 1u);
+                if (put1) i1 = atomicAdd(&s_total, 1u);
+                if (put0 && i0 < T3_POOL) s_pool[i0] = (lbx0 << 15) | tag | ci0;
+                if (put1 && i1 < T3_POOL) s_pool[i1] = (lbx1 << 15) | tag | ci1;
+                if ((uint32_t)(__ballot((put0 && i0 >= T3_POOL) || (put1 && i1 >= T3_POOL)) >> hbase) != 0u) mycnt = T3_CAP + 1;
             }
         }
-        if (l32 == 0 && mycnt > SEA_LIST) s_ovf[hw] = 1;
+        if (l32 == 0 && mycnt > T3_CAP) s_ovf[hw] = 1;
     }
     __syncthreads();
     if (S.me_stop == 5) {
@@ -334,7 +342,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves ---- */
     {
-        const uint32_t total = s_total;
+        const uint32_t total = min(s_total, (uint32_t)T3_POOL);
         for (uint32_t k = (uint32_t)(tid >> 4); k < ((total + 31u) & ~31u); k += 32u) {
             const uint32_t e = k < total ? s_pool[k] : 0xffffffffu;
             const int ehw = (int)((e >> 11) & 15u), ci = (int)(e & 2047u);
@@ -350,12 +358,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __syncthreads();
     if (l32 == 0 && mb_valid) {
         const uint32_t best = s_best[hw];
-        const bool overflow = mycnt > SEA_LIST;
         const uint32_t cand = B.me_cand[best & 2047u];
         const int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
         B.mvsad[mbidx] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
-        B.me_flag[mbidx] = overflow ? 1 : 0;
+        const bool overflow = mycnt > T3_CAP;
+        B.me_flag[mbidx] = overflow ? 1 : 0; /* k_me_fix searches it exhaustively */
         if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(my * g.mbw + mx);
-        B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* survivors of the bound test besides the start points (introspection) */
+        B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
     }
 }
