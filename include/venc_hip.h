@@ -157,9 +157,10 @@ int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_t dst_bytes
  * names via venc_profile_name) and clears the log.  Returns 1 if the log
  * overflowed its capacity. */
 int venc_profile(venc_ctx *c, int enable, int capacity);
-/* restrict the event pairs to the kernels whose id bit is set (default: all); every pair costs the
- * stream a few microseconds, so the timed region of bench.py selects the dominant kernel only */
-int venc_profile_select(venc_ctx *c, unsigned kernel_mask);
+/* restrict the event pairs to the kernels whose id bit is set (default: all) and to every stride-th
+ * launch of each (default: 1); every pair costs the stream a few microseconds, so the timed region of
+ * bench.py samples the dominant kernel only */
+int venc_profile_select(venc_ctx *c, unsigned kernel_mask, int stride);
 int venc_profile_kernels(void);
 const char *venc_profile_name(int kernel_id);
 int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches);

@@ -152,7 +152,7 @@ def hip_lib():
         L.venc_profile_name.restype = C.c_char_p
         L.venc_profile_name.argtypes = [C.c_int]
         L.venc_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
-        L.venc_profile_select.argtypes = [C.c_void_p, C.c_uint]
+        L.venc_profile_select.argtypes = [C.c_void_p, C.c_uint, C.c_int]
         L.venc_set_band.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.venc_band_rows.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.venc_band_chunk_bytes.restype = C.c_size_t
@@ -463,8 +463,9 @@ class X264Encoder:
         if hip_lib().venc_profile(self.L.x264_venc_engine(self.h), int(enable), capacity) != 0:
             raise VencError("venc_profile failed")
 
-    def profile_select(self, names=None):
-        """Event pairs only around the named kernels (None = all): each pair costs the stream a few microseconds."""
+    def profile_select(self, names=None, stride=1):
+        """Event pairs only around every stride-th launch of the named kernels (None = all): each pair costs the
+        stream a few microseconds."""
         H = hip_lib()
         mask = 0xffffffff
         if names is not None:
@@ -472,7 +473,7 @@ class X264Encoder:
             mask = 0
             for n in names:
                 mask |= 1 << all_names.index(n)
-        if H.venc_profile_select(self.L.x264_venc_engine(self.h), mask) != 0:
+        if H.venc_profile_select(self.L.x264_venc_engine(self.h), mask, stride) != 0:
             raise VencError("venc_profile_select failed")
 
     def set_overlap(self, enable):

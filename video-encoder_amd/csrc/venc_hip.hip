@@ -79,6 +79,7 @@ struct venc_ctx {
                      search.  Env VENC_ME=pool|tile|plane|dense (VENC_ME_DENSE=1 = dense). */
     /* optional per-kernel HIP-event timing (venc_profile) */
     int prof_on;
+    int prof_stride, prof_seen[16]; /* event pairs around every prof_stride-th launch of a selected kernel */
     unsigned prof_mask; /* kernels that get event pairs (bit = kernel id); every pair costs the stream a few microseconds */
     hipEvent_t *prof_ev; /* pairs */
     int *prof_kid;
@@ -92,6 +93,7 @@ static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intr
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
     c->prof_open = 0;
     if (!c->prof_on || !((c->prof_mask >> kid) & 1u) || c->prof_n >= c->prof_cap) return;
+    if (c->prof_seen[kid]++ % c->prof_stride) return;
     c->prof_open = 1;
     c->prof_kid[c->prof_n] = kid;
     (void)hipEventRecord(c->prof_ev[2 * c->prof_n], st);
@@ -760,12 +762,16 @@ extern "C" int venc_profile(venc_ctx *c, int enable, int capacity) {
     }
     c->prof_on = enable ? 1 : 0;
     c->prof_mask = 0xffffffffu;
+    c->prof_stride = 1;
+    memset(c->prof_seen, 0, sizeof(c->prof_seen));
     c->prof_n = 0;
     return 0;
 }
 
-extern "C" int venc_profile_select(venc_ctx *c, unsigned kernel_mask) {
+extern "C" int venc_profile_select(venc_ctx *c, unsigned kernel_mask, int stride) {
     c->prof_mask = kernel_mask;
+    c->prof_stride = stride > 0 ? stride : 1;
+    memset(c->prof_seen, 0, sizeof(c->prof_seen));
     return 0;
 }
 extern "C" int venc_profile_kernels(void) { return KID_COUNT; }
