@@ -41,6 +41,15 @@ def test_x264_shim_exports_the_reference_entry_points(venc):
     assert want <= _exported(venc.LIB_X264), want - _exported(venc.LIB_X264)
 
 
+def test_io_library_exports_the_muxer_and_source_entry_points(venc):
+    venc.build()
+    want = _declared("venc_mp4.h") | _declared("venc_source.h")
+    assert {"venc_mp4_open", "venc_mp4_write_video_sample", "venc_mp4_mux_video", "venc_mp4_close", "venc_source_open",
+            "venc_source_read", "venc_source_close"} <= want
+    assert want <= _exported(venc.LIB_IO), want - _exported(venc.LIB_IO)
+    venc.io_lib()
+
+
 def test_param_functions_follow_the_reference_contract(venc):
     L = venc.x264_lib()
     p = venc.X264Param()

@@ -303,3 +303,40 @@ def test_lane_per_macroblock_cavlc_equals_half_wave_cavlc(venc):
             for t in range(n):
                 assert np.array_equal(outs[0][t][0], outs[1][t][0]), "%s qp%d frame %d: macroblock bit counts" % (name, qp, t)
                 assert outs[0][t][1] == outs[1][t][1], "%s qp%d frame %d: slice bytes" % (name, qp, t)
+
+
+def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
+    """tools/encode_yuv: the reference's call sequence in C, YUV4MPEG2 in (include/venc_source.h), MP4 out
+    (include/venc_mp4.h).  The samples in the file equal the oracle's slice NALs, the avcC parameter sets equal the
+    oracle's, and the demultiplexed stream decodes to the oracle's reconstruction."""
+    import json
+    import os
+    import struct
+    import subprocess
+    from test_io import read_track, samples_of, _write_y4m
+    w, h, n, keyint, slices = 176, 144, 7, 3, 3
+    frames = [venc.synth_frame(w, h, t, 99) for t in range(n)]
+    y4m, mp4, es = str(tmp_path / "in.y4m"), str(tmp_path / "out.mp4"), str(tmp_path / "out.h264")
+    _write_y4m(y4m, frames, w, h, header_extra="F24:1 Ip A1:1 C420mpeg2")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "encode_yuv")
+    out = subprocess.check_output([tool, "-i", y4m, "-n", "100", "-q", "27", "-S", str(slices), "-k", str(keyint), "-t", "zerolatency",
+                                   "-o", es, "-m", mp4])
+    rep = json.loads(out.decode().strip().splitlines()[-1])
+    assert rep["frames"] == n and rep["violations"] == 0 and rep["sync_samples"] == 3
+    data = open(mp4, "rb").read()
+    t = read_track(data)
+    assert t["timescale"] == 24 and t["stts"] == [(n, 1)] and t["stss"] == [1, 4, 7] and (t["width"], t["height"]) == (w, h)
+    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4)
+    dec = orc.Decoder()
+    got = samples_of(data, t)
+    for k, f in enumerate(frames):
+        ref = enc.encode(*f)
+        first = min(off for (ty, _, off, _) in ref.nals if ty not in (7, 8))
+        assert got[k] == ref.data[first:], "sample %d differs from the oracle's slices" % k
+        if k == 0:
+            sps = [bytes([0x67]) + b for (ty, _, b) in split_nals(ref.data) if ty == 7]
+            pps = [bytes([0x68]) + b for (ty, _, b) in split_nals(ref.data) if ty == 8]
+            assert t["sps"] == sps and t["pps"] == pps
+            assert dec.decode(b"".join(struct.pack(">I", len(x)) + x for x in sps + pps)) == 0
+        assert dec.decode(got[k]) == 1
+        assert np.array_equal(dec.planes()[0], enc.recon()[0])

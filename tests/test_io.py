@@ -1,0 +1,264 @@
+"""CPU tests of the host-side I/O either side of the encode path:
+the ISO-BMFF writer (include/venc_mp4.h, replaces libmp4v2 in av_encode.c:614-834) and the
+YUV4MPEG2 / I420 frame source (include/venc_source.h, replaces the pull-and-copy at av_encode.c:525-560).
+The MP4 files are checked with a box parser written here and by demultiplexing them again and
+decoding the result with the oracle's decoder (oracle/: this repository's own restatement; parity
+with libx264 / libmp4v2 unpinned -- neither library exists in the build image)."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import noise_frames, split_nals
+
+
+# ----------------------------------------------------------------------------- a small ISO-BMFF reader
+CONTAINERS = {b"moov", b"trak", b"mdia", b"minf", b"dinf", b"stbl"}
+
+
+def parse_boxes(data, start=0, end=None, path=b""):
+    """{path: (payload_offset, payload_size)} of every box, descending into the plain containers."""
+    out = {}
+    end = len(data) if end is None else end
+    o = start
+    while o < end:
+        size, typ = struct.unpack(">I4s", data[o:o + 8])
+        hdr = 8
+        if size == 1:
+            size = struct.unpack(">Q", data[o + 8:o + 16])[0]
+            hdr = 16
+        assert size >= hdr and o + size <= end, "box %r overruns its parent" % typ
+        p = path + b"/" + typ
+        out[p] = (o + hdr, size - hdr)
+        if typ in CONTAINERS:
+            out.update(parse_boxes(data, o + hdr, o + size, p))
+        o += size
+    assert o == end
+    return out
+
+
+def read_track(data):
+    b = parse_boxes(data)
+    stbl = b"/moov/trak/mdia/minf/stbl"
+
+    def full(name):
+        off, size = b[stbl + b"/" + name]
+        assert data[off:off + 4] in (b"\0\0\0\0",), name
+        return off + 4, size - 4
+
+    t = {"boxes": b}
+    off, _ = b[b"/moov/trak/mdia/mdhd"]
+    t["timescale"], t["duration"] = struct.unpack(">II", data[off + 12:off + 20])
+    off, _ = b[b"/moov/mvhd"]
+    t["movie_timescale"] = struct.unpack(">I", data[off + 12:off + 16])[0]
+    off, _ = b[b"/moov/trak/tkhd"]
+    t["tk_width"], t["tk_height"] = struct.unpack(">II", data[off + 76:off + 84])
+    off, _ = b[b"/moov/trak/mdia/hdlr"]
+    t["handler"] = data[off + 8:off + 12]
+    # stsd -> avc1 -> avcC, pasp
+    off, size = full(b"stsd")
+    assert struct.unpack(">I", data[off:off + 4])[0] == 1
+    esz, etyp = struct.unpack(">I4s", data[off + 4:off + 12])
+    assert etyp == b"avc1"
+    e = off + 12
+    t["width"], t["height"] = struct.unpack(">HH", data[e + 24:e + 28])
+    sub = parse_boxes(data, e + 78, off + 4 + esz)
+    ao, asz = sub[b"/avcC"]
+    a = data[ao:ao + asz]
+    t["avcC"] = dict(version=a[0], profile=a[1], compat=a[2], level=a[3], length_size=(a[4] & 3) + 1)
+    n_sps = a[5] & 31
+    o = 6
+    t["sps"], t["pps"] = [], []
+    for _ in range(n_sps):
+        n = struct.unpack(">H", a[o:o + 2])[0]
+        t["sps"].append(a[o + 2:o + 2 + n])
+        o += 2 + n
+    n_pps = a[o]
+    o += 1
+    for _ in range(n_pps):
+        n = struct.unpack(">H", a[o:o + 2])[0]
+        t["pps"].append(a[o + 2:o + 2 + n])
+        o += 2 + n
+    assert o == len(a)
+    po, _ = sub[b"/pasp"]
+    t["pasp"] = struct.unpack(">II", data[po:po + 8])
+    off, _ = full(b"stts")
+    n = struct.unpack(">I", data[off:off + 4])[0]
+    t["stts"] = [struct.unpack(">II", data[off + 4 + 8 * i:off + 12 + 8 * i]) for i in range(n)]
+    off, _ = full(b"stss")
+    n = struct.unpack(">I", data[off:off + 4])[0]
+    t["stss"] = list(struct.unpack(">%dI" % n, data[off + 4:off + 4 + 4 * n]))
+    off, _ = full(b"stsz")
+    fixed, n = struct.unpack(">II", data[off:off + 8])
+    assert fixed == 0
+    t["stsz"] = list(struct.unpack(">%dI" % n, data[off + 8:off + 8 + 4 * n]))
+    off, _ = full(b"stsc")
+    n = struct.unpack(">I", data[off:off + 4])[0]
+    t["stsc"] = [struct.unpack(">III", data[off + 4 + 12 * i:off + 16 + 12 * i]) for i in range(n)]
+    off, _ = full(b"co64")
+    n = struct.unpack(">I", data[off:off + 4])[0]
+    t["co64"] = list(struct.unpack(">%dQ" % n, data[off + 4:off + 4 + 8 * n]))
+    t["has_ctts"] = (stbl + b"/ctts") in b
+    return t
+
+
+def samples_of(data, t):
+    assert t["stsc"] == [(1, len(t["stsz"]), 1)] and len(t["co64"]) == 1
+    o = t["co64"][0]
+    out = []
+    for n in t["stsz"]:
+        out.append(data[o:o + n])
+        o += n
+    mo, ms = t["boxes"][b"/mdat"]
+    assert mo == t["co64"][0] and o == mo + ms, "the samples fill the mdat box exactly"
+    return out
+
+
+def _encode_and_mux(venc, orc, path, w, h, n, keyint, slices, fps):
+    clip = noise_frames(w, h, n, seed=3)
+    enc = orc.Encoder(w, h, qp=28, n_slices=slices, keyint=keyint, fps=fps, sar=(4, 3))
+    mp4 = venc.Mp4Writer(path, w, h, time_base=(fps[1], fps[0]), sar=(4, 3))
+    frames, recons = [], []
+    for t, f in enumerate(clip):
+        fr = enc.encode(*f)
+        frames.append(fr)
+        recons.append(enc.recon())
+        mp4.mux(fr.data, fr.nals, t, t, fr.is_idr)
+        assert mp4.samples() == max(0, t)  # one frame is always held back (av_encode.c:771-783)
+    mp4.flush()
+    assert mp4.samples() == n
+    mp4.close()
+    return frames, recons
+
+
+@pytest.mark.parametrize("fps", [(30, 1), (30000, 1001)])
+def test_mp4_file_structure_and_round_trip(venc, orc, tmp_path, fps):
+    w, h, n, keyint, slices = 64, 48, 9, 4, 2
+    path = str(tmp_path / "out.mp4")
+    frames, recons = _encode_and_mux(venc, orc, path, w, h, n, keyint, slices, fps)
+    data = open(path, "rb").read()
+    assert data[4:8] == b"ftyp" and data[8:12] == b"isom"
+    t = read_track(data)
+    assert t["handler"] == b"vide" and (t["width"], t["height"]) == (w, h)
+    # time scale = time_base num * den, durations in ticks = delta dts * num (venc_mp4.h deviation note)
+    num, den = fps[1], fps[0]
+    assert t["timescale"] == num * den == t["movie_timescale"]
+    assert t["stts"] == [(n, num)] and t["duration"] == n * num and not t["has_ctts"]
+    assert t["stss"] == [1 + k for k in range(0, n, keyint)]
+    assert t["pasp"] == (4, 3) and t["tk_width"] == ((w * 4 << 16) // 3) and t["tk_height"] == h << 16
+    # avcC: from the first SPS (bytes 5..7 of the prefixed NAL), 4-byte lengths, each parameter set once
+    nal0 = split_nals(frames[0].data)
+    sps = [bytes([0x67]) + b for (ty, _, b) in nal0 if ty == 7]
+    pps = [bytes([0x68]) + b for (ty, _, b) in nal0 if ty == 8]
+    assert t["avcC"] == dict(version=1, profile=sps[0][1], compat=sps[0][2], level=sps[0][3], length_size=4)
+    assert t["sps"] == sps and t["pps"] == pps
+    # samples = the slice NALs of each frame, length prefixes included, parameter sets stripped
+    got = samples_of(data, t)
+    for f, s in zip(frames, got):
+        first = min(off for (ty, _, off, _) in f.nals if ty not in (7, 8, 12))
+        assert s == f.data[first:]
+    # demultiplex and decode again: parameter sets from avcC + samples -> the oracle's decoder
+    dec = orc.Decoder()
+    hdr = b"".join(struct.pack(">I", len(x)) + x for x in t["sps"] + t["pps"])
+    assert dec.decode(hdr) == 0
+    for k, s in enumerate(got):
+        assert dec.decode(s) == 1
+        for p in range(3):
+            assert np.array_equal(dec.planes()[p], recons[k][p]), "frame %d plane %d" % (k, p)
+
+
+def test_mp4_writer_rejects_what_the_reference_muxer_cannot_take(venc, orc, tmp_path):
+    w, h = 32, 32
+    enc = orc.Encoder(w, h, qp=30, n_slices=1, keyint=8)
+    clip = noise_frames(w, h, 3, seed=9)
+    fr = [enc.encode(*f) for f in clip]
+    m = venc.Mp4Writer(str(tmp_path / "a.mp4"), w, h)
+    m.mux(fr[0].data, fr[0].nals, 0, 0, True)
+    with pytest.raises(venc.VencError):
+        m.mux(fr[1].data, fr[1].nals, 0, 0, False)   # decode time does not increase: no valid sample duration
+    m.close()
+    with pytest.raises(venc.VencError):
+        venc.Mp4Writer(str(tmp_path / "no" / "such" / "dir.mp4"), w, h)
+    with pytest.raises(venc.VencError):
+        venc.Mp4Writer(str(tmp_path / "b.mp4"), w, h, time_base=(0, 30))
+    # close() writes a frame the caller forgot to flush
+    m = venc.Mp4Writer(str(tmp_path / "c.mp4"), w, h)
+    m.mux(fr[0].data, fr[0].nals, 0, 0, True)
+    m.close()
+    assert read_track(open(str(tmp_path / "c.mp4"), "rb").read())["stsz"] != []
+
+
+# ----------------------------------------------------------------------------- frame source
+class _Pic:
+    """x264_picture_t with numpy-backed planes and arbitrary strides (stands in for x264_picture_alloc on CPU)."""
+
+    def __init__(self, venc, w, h, pad=0):
+        self.pic = venc.X264Picture()
+        self.arr = [np.full((h, w + pad), 0xEE, np.uint8), np.full((h // 2, w // 2 + pad), 0xEE, np.uint8),
+                    np.full((h // 2, w // 2 + pad), 0xEE, np.uint8)]
+        self.pic.img.i_csp, self.pic.img.i_plane = 1, 3
+        for i, a in enumerate(self.arr):
+            self.pic.img.i_stride[i] = a.strides[0]
+            self.pic.img.plane[i] = a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _write_y4m(path, frames, w, h, header_extra="F25:1 Ip A16:15 C420jpeg XYSCSS=420JPEG", frame_extra=""):
+    with open(path, "wb") as f:
+        f.write(("YUV4MPEG2 W%d H%d %s\n" % (w, h, header_extra)).encode())
+        for y, u, v in frames:
+            f.write(("FRAME%s\n" % frame_extra).encode())
+            f.write(y.tobytes() + u.tobytes() + v.tobytes())
+
+
+@pytest.mark.parametrize("pad", [0, 24])
+def test_y4m_and_raw_sources_fill_strided_pictures(venc, tmp_path, pad):
+    w, h, n = 50, 38, 4  # not multiples of 16: the encoder pads, the source must not
+    frames = noise_frames(64, 48, n, seed=2)
+    frames = [(y[:h, :w].copy(), u[:h // 2, :w // 2].copy(), v[:h // 2, :w // 2].copy()) for y, u, v in frames]
+    y4m, raw = str(tmp_path / "a.y4m"), str(tmp_path / "a.yuv")
+    _write_y4m(y4m, frames, w, h, frame_extra=" Ip")
+    with open(raw, "wb") as f:
+        for y, u, v in frames:
+            f.write(y.tobytes() + u.tobytes() + v.tobytes())
+    for path, size in ((y4m, (0, 0)), (raw, (w, h))):
+        src = venc.FrameSource(path, *size)
+        assert (src.width, src.height) == (w, h)
+        assert src.fps == ((25, 1) if path == y4m else (30, 1)) and src.sar == ((16, 15) if path == y4m else (1, 1))
+        p = _Pic(venc, w, h, pad)
+        for k in range(n):
+            assert src.read_into(p.pic)
+            for a, want in zip(p.arr, frames[k]):
+                assert np.array_equal(a[:, :want.shape[1]], want)
+                assert (a[:, want.shape[1]:] == 0xEE).all()  # bytes between the rows stay untouched
+        assert not src.read_into(p.pic)  # end of stream
+        src.close()
+
+
+def test_sources_refuse_what_they_cannot_read(venc, tmp_path):
+    w, h = 16, 16
+    f = [(np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8))]
+    for extra in ("C444", "C420p10", "It C420"):
+        p = str(tmp_path / ("bad_%s.y4m" % extra.replace(" ", "_")))
+        _write_y4m(p, f, w, h, header_extra=extra)
+        with pytest.raises(venc.VencError):
+            venc.FrameSource(p)
+    with pytest.raises(venc.VencError):
+        venc.FrameSource(str(tmp_path / "missing.y4m"))
+    p = str(tmp_path / "odd.y4m")
+    _write_y4m(p, f, 15, 16)
+    with pytest.raises(venc.VencError):
+        venc.FrameSource(p)
+    # truncated frame
+    p = str(tmp_path / "short.y4m")
+    _write_y4m(p, f, w, h)
+    data = open(p, "rb").read()
+    open(p, "wb").write(data[:-10])
+    src = venc.FrameSource(p)
+    with pytest.raises(venc.VencError):
+        src.read_into(_Pic(venc, w, h).pic)
+    # not a y4m stream and no size given
+    p = str(tmp_path / "raw.yuv")
+    open(p, "wb").write(bytes(384))
+    with pytest.raises(venc.VencError):
+        venc.FrameSource(p)

@@ -16,8 +16,13 @@
  * one relies on before writing the samples as an
  * Annex-B elementary stream (or nothing with -o -).
  *
- * usage: encode_yuv [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint]
- *                   [-g gop_batch] [-t tune] [-i in.yuv] [-o out.h264] [-f fps]
+ * With -m the samples also go through the ISO-BMFF writer of this repository (include/venc_mp4.h,
+ * the reference's enc_mp4_open / enc_mp4_mux_video / MP4Close) into a playable .mp4; -i takes a
+ * YUV4MPEG2 file (size, rate and aspect from its header) or, with -s, headerless I420
+ * (include/venc_source.h, the reference's pull-and-copy at av_encode.c:525-560).
+ *
+ * usage: encode_yuv [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint] [-g gop_batch] [-t tune]
+ *                   [-i in.y4m|in.yuv] [-o out.h264] [-m out.mp4] [-f fps]
  */
 #define _POSIX_C_SOURCE 200809L
 #include <stdbool.h>
@@ -28,6 +33,8 @@
 #include <time.h>
 
 #include "venc_hip.h"
+#include "venc_mp4.h"
+#include "venc_source.h"
 #include "x264.h"
 
 typedef struct {
@@ -38,8 +45,8 @@ typedef struct {
     int payload_size;
 } x264_context_t; /* av_encode.c:369-376 without the swscale handle */
 
-static bool enc_x264_open(int width, int height, int fps_num, int fps_den, const char *preset, const char *tune, int quality,
-                          const char *profile, int slices, int keyint, int gop_batch, x264_context_t *x) {
+static bool enc_x264_open(int width, int height, int fps_num, int fps_den, int sar_num, int sar_den, const char *preset, const char *tune,
+                          int quality, const char *profile, int slices, int keyint, int gop_batch, x264_context_t *x) {
     x264_param_t params;
     if (x264_param_default_preset(&params, preset, tune) != 0) {
         fprintf(stderr, "x264: failed to set preset %s and tune %s\n", preset, tune);
@@ -50,8 +57,8 @@ static bool enc_x264_open(int width, int height, int fps_num, int fps_den, const
     params.b_annexb = false;
     params.i_fps_num = fps_num;
     params.i_fps_den = fps_den;
-    params.vui.i_sar_width = 1;
-    params.vui.i_sar_height = 1;
+    params.vui.i_sar_width = sar_num;
+    params.vui.i_sar_height = sar_den;
     params.rc.i_rc_method = X264_RC_CRF;
     params.rc.f_rf_constant = (float)quality;
     params.i_slice_count = slices;
@@ -89,6 +96,7 @@ typedef struct {
 } x264_frame_t;
 
 static FILE *g_out = NULL;
+static venc_mp4 *g_mp4 = NULL;
 static long g_samples = 0, g_sync_samples = 0, g_bytes = 0, g_violations = 0;
 static bool g_track_configured = false;
 
@@ -152,6 +160,8 @@ static void write_sample(x264_nal_t *nals, int nal_count, size_t payload_size, b
 
 static bool mux_video(x264_context_t *x) {
     static x264_frame_t prev = {NULL, 0, NULL, 0, {0}};
+    /* the real container, when asked for: same call, same arguments as the reference's enc_mp4_mux_video */
+    if (g_mp4 && venc_mp4_mux_video(g_mp4, x->nals, x->nal_count, x->payload_size, &x->pic_out) != 0) return false;
     if (x->payload_size > 0) {
         if (prev.payload_size > 0)
             write_sample(prev.nal_data, (int)prev.nal_count, prev.payload_size, prev.pic.b_keyframe,
@@ -187,8 +197,9 @@ static double now_s(void) {
 }
 
 int main(int argc, char **argv) {
-    int w = 352, h = 288, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 1, fps = 30;
-    const char *in = NULL, *out = NULL, *tune = "film";
+    int w = 0, h = 0, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 1, fps = 30, fps_den = 1, sar_num = 1, sar_den = 1;
+    int fps_given = 0;
+    const char *in = NULL, *out = NULL, *mp4 = NULL, *tune = "film";
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i], *v = i + 1 < argc ? argv[i + 1] : NULL;
         if (!strcmp(a, "-s") && v && sscanf(v, "%dx%d", &w, &h) == 2) i++;
@@ -197,36 +208,41 @@ int main(int argc, char **argv) {
         else if (!strcmp(a, "-S") && v) slices = atoi(v), i++;
         else if (!strcmp(a, "-k") && v) keyint = atoi(v), i++;
         else if (!strcmp(a, "-g") && v) gop_batch = atoi(v), i++;
-        else if (!strcmp(a, "-f") && v) fps = atoi(v), i++;
+        else if (!strcmp(a, "-f") && v) fps = atoi(v), fps_given = 1, i++;
         else if (!strcmp(a, "-t") && v) tune = v, i++;
         else if (!strcmp(a, "-i") && v) in = v, i++;
         else if (!strcmp(a, "-o") && v) out = v, i++;
+        else if (!strcmp(a, "-m") && v) mp4 = v, i++;
         else {
-            fprintf(stderr, "usage: %s [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint] [-g gop_batch] [-t tune] [-f fps] [-i in.yuv] [-o out.h264]\n", argv[0]);
+            fprintf(stderr, "usage: %s [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint] [-g gop_batch] [-t tune] [-f fps] [-i in.y4m|in.yuv] [-o out.h264] [-m out.mp4]\n", argv[0]);
             return 1;
         }
     }
-    FILE *fin = NULL;
-    if (in && !(fin = fopen(in, "rb"))) {
-        perror(in);
-        return 2;
+    venc_source *src = NULL;
+    if (in) {
+        if (!(src = venc_source_open(in, w, h))) return 2; /* -s given: headerless I420; else YUV4MPEG2 */
+        w = venc_source_width(src), h = venc_source_height(src);
+        if (!fps_given) venc_source_rate(src, &fps, &fps_den); /* the stream header's rate (30:1 for headerless I420) unless -f */
+        venc_source_aspect(src, &sar_num, &sar_den);
     }
+    if (!w || !h) w = 352, h = 288;
     if (out && strcmp(out, "-") && !(g_out = fopen(out, "wb"))) {
         perror(out);
         return 2;
     }
     x264_context_t x264;
     memset(&x264, 0, sizeof(x264));
-    if (!enc_x264_open(w, h, fps, 1, "medium", tune, qp, NULL, slices, keyint, gop_batch, &x264)) return 6;
+    if (!enc_x264_open(w, h, fps, fps_den, sar_num, sar_den, "medium", tune, qp, NULL, slices, keyint, gop_batch, &x264)) return 6;
+    /* track time base = 1 / frame rate, as the reference's codec context has it (av_encode.c:638) */
+    if (mp4 && !(g_mp4 = venc_mp4_open(mp4, w, h, fps_den, fps, sar_num, sar_den))) return 2;
 
     const double t0 = now_s();
     int64_t encoded_video_pts = 0;
     for (int f = 0; f < frames; f++) {
         x264.pic_in.i_type = X264_TYPE_AUTO;
         x264.pic_in.i_pts = f;
-        if (fin) {
-            size_t want = (size_t)w * h * 3 / 2;
-            if (fread(x264.pic_in.img.plane[0], 1, want, fin) != want) break;
+        if (src) {
+            if (venc_source_read(src, &x264.pic_in) != 1) break; /* end of stream (or a truncated frame: reported on stderr) */
         } else {
             venc_synth_frame(w, h, f, 0x1234ABCDu, x264.pic_in.img.plane[0], x264.pic_in.img.plane[1], x264.pic_in.img.plane[2]);
         }
@@ -249,7 +265,8 @@ int main(int argc, char **argv) {
     const double dt = now_s() - t0;
     enc_x264_close(&x264);
     if (g_out) fclose(g_out);
-    if (fin) fclose(fin);
+    if (g_mp4 && venc_mp4_close(g_mp4) != 0) g_violations++;
+    if (src) venc_source_close(src);
     printf("{\"frames\": %ld, \"sync_samples\": %ld, \"bytes\": %ld, \"last_pts\": %lld, \"seconds\": %.4f, \"mpixels_per_s\": %.2f, \"violations\": %ld}\n",
            g_samples, g_sync_samples, g_bytes, (long long)encoded_video_pts, dt, g_samples * (double)w * h / dt / 1e6, g_violations);
     return g_violations ? 3 : 0;

@@ -26,6 +26,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_HIP = os.path.join(CSRC, os.environ.get("VENC_HIP_LIB", "libvenc_hip.so"))  # VENC_HIP_LIB: diagnostic builds
 LIB_X264 = os.path.join(CSRC, "libx264_venc.so")
 LIB_HOSTCHECK = os.path.join(CSRC, "libvenc_hostcheck.so")
+LIB_IO = os.path.join(CSRC, "libvenc_io.so")
 
 MB_COEFS = 27 * 16
 MAX_ITEMS = 64
@@ -112,6 +113,7 @@ SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(X264Nal), C.c_int, C.c_int,
 
 _hip = None
 _x264 = None
+_io = None
 
 
 def _load(path):
@@ -188,6 +190,107 @@ def x264_lib():
         L.x264_venc_engine.argtypes = [C.c_void_p]
         _x264 = L
     return _x264
+
+
+def io_lib():
+    """Host-only C library: MP4 writer (include/venc_mp4.h) and frame source (include/venc_source.h).  No GPU needed."""
+    global _io
+    if _io is None:
+        if not os.path.exists(LIB_IO):
+            raise VencError("%s is missing: run __graft_entry__.build() (make -C %s)" % (LIB_IO, CSRC))
+        L = C.CDLL(LIB_IO)
+        L.venc_mp4_open.restype = C.c_void_p
+        L.venc_mp4_open.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.venc_mp4_write_video_sample.argtypes = [C.c_void_p, C.POINTER(X264Nal), C.c_int, C.c_size_t, C.c_int, C.c_int64,
+                                                  C.c_int64]
+        L.venc_mp4_mux_video.argtypes = [C.c_void_p, C.POINTER(X264Nal), C.c_int, C.c_int, C.POINTER(X264Picture)]
+        L.venc_mp4_close.argtypes = [C.c_void_p]
+        L.venc_mp4_sample_count.restype = C.c_long
+        L.venc_mp4_sample_count.argtypes = [C.c_void_p]
+        L.venc_source_open.restype = C.c_void_p
+        L.venc_source_open.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.venc_source_close.argtypes = [C.c_void_p]
+        L.venc_source_width.argtypes = [C.c_void_p]
+        L.venc_source_height.argtypes = [C.c_void_p]
+        L.venc_source_rate.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.venc_source_aspect.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.venc_source_read.argtypes = [C.c_void_p, C.POINTER(X264Picture)]
+        _io = L
+    return _io
+
+
+class Mp4Writer:
+    """include/venc_mp4.h: the reference's enc_mp4_open / enc_mp4_mux_video / MP4Close (av_encode.c:614-834, :1104)."""
+
+    def __init__(self, filename, width, height, time_base=(1, 30), sar=(1, 1)):
+        self.L = io_lib()
+        self.h = self.L.venc_mp4_open(os.fsencode(filename), width, height, time_base[0], time_base[1], sar[0], sar[1])
+        if not self.h:
+            raise VencError("venc_mp4_open failed for %s" % filename)
+
+    def mux(self, payload, nals, pts, dts, keyframe):
+        """One encoded frame: payload bytes + [(type, ref_idc, offset, size)] as delivered by the encoder."""
+        buf = (C.c_uint8 * len(payload)).from_buffer_copy(payload)
+        arr = (X264Nal * len(nals))()
+        base = C.addressof(buf)
+        for i, (ty, ref, off, size) in enumerate(nals):
+            arr[i].i_type, arr[i].i_ref_idc, arr[i].i_payload = ty, ref, size
+            arr[i].p_payload = C.cast(base + off, C.POINTER(C.c_uint8))
+        pic = X264Picture()
+        pic.i_pts, pic.i_dts, pic.b_keyframe = pts, dts, int(keyframe)
+        if self.L.venc_mp4_mux_video(self.h, arr, len(nals), len(payload), C.byref(pic)) != 0:
+            raise VencError("venc_mp4_mux_video failed")
+
+    def flush(self):
+        if self.L.venc_mp4_mux_video(self.h, None, 0, 0, None) != 0:
+            raise VencError("venc_mp4_mux_video (flush) failed")
+
+    def samples(self):
+        return self.L.venc_mp4_sample_count(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            rc = self.L.venc_mp4_close(self.h)
+            self.h = None
+            if rc != 0:
+                raise VencError("venc_mp4_close failed")
+
+    def __del__(self):
+        try:
+            self.close()
+        except VencError:
+            pass
+
+
+class FrameSource:
+    """include/venc_source.h: YUV4MPEG2 or headerless I420 frames into an x264_picture_t (av_encode.c:525-560)."""
+
+    def __init__(self, filename, width=0, height=0):
+        self.L = io_lib()
+        self.h = self.L.venc_source_open(os.fsencode(filename), width, height)
+        if not self.h:
+            raise VencError("venc_source_open failed for %s" % filename)
+        self.width, self.height = self.L.venc_source_width(self.h), self.L.venc_source_height(self.h)
+        a, b = C.c_int(0), C.c_int(0)
+        self.L.venc_source_rate(self.h, C.byref(a), C.byref(b))
+        self.fps = (a.value, b.value)
+        self.L.venc_source_aspect(self.h, C.byref(a), C.byref(b))
+        self.sar = (a.value, b.value)
+
+    def read_into(self, pic):
+        """pic: X264Picture with allocated planes.  True: frame read; False: end of stream."""
+        rc = self.L.venc_source_read(self.h, C.byref(pic))
+        if rc < 0:
+            raise VencError("venc_source_read failed (truncated or malformed input)")
+        return rc == 1
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.venc_source_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def synth_frame(width, height, frame_index, seed=0x1234ABCD):
