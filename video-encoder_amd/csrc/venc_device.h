@@ -25,8 +25,14 @@
 
 #if defined(__HIPCC__)
 #define VENC_DEV __device__ __forceinline__
+/* 24-bit multiplies (v_mul_u32_u24 / v_mul_i32_i24, v_mad_*: full rate; v_mul_lo_u32 issues at a quarter of it).  Every
+ * use below has both factors inside 24 bits and the product inside 32, see the range note at each call. */
+#define VENC_UMUL24(a, b) __umul24((unsigned)(a), (unsigned)(b))
+#define VENC_MUL24(a, b) __mul24((int)(a), (int)(b))
 #else
 #define VENC_DEV static inline
+#define VENC_UMUL24(a, b) ((unsigned)(a) * (unsigned)(b))
+#define VENC_MUL24(a, b) ((int)(a) * (int)(b))
 #endif
 
 /* quantiser constants of one QP, computed on the host once per encoder */
@@ -95,27 +101,29 @@ VENC_DEV void venc_idct4(const int d[16], int r[16]) {
 /* ---------------------------------------------------------------- quantiser */
 VENC_DEV int venc_quant_mag(int w, int mf, int f, int shift) {
     unsigned a = (unsigned)(w < 0 ? -w : w);
-    int lv = (int)((a * (unsigned)mf + (unsigned)f) >> shift);
+    /* |w| <= 65280 (Hadamard of 16 luma DCs of 4080), mf <= 13107: product < 2^30 */
+    int lv = (int)((VENC_UMUL24(a, mf) + (unsigned)f) >> shift);
     return w < 0 ? -lv : lv;
 }
 /* AC / normal coefficient at raster position r */
 VENC_DEV int venc_quant(int w, const venc_qparams *q, int r, int intra) {
     return venc_quant_mag(w, q->mf[venc_pos_class(r)], intra ? q->f_intra : q->f_inter, q->qbits);
 }
-VENC_DEV int venc_dequant(int lv, const venc_qparams *q, int r) { return (lv * q->v[venc_pos_class(r)]) << q->per; }
+VENC_DEV int venc_dequant(int lv, const venc_qparams *q, int r) { return VENC_MUL24(lv, q->v[venc_pos_class(r)]) << q->per; } /* |lv| < 2^16, v <= 29 */
 /* Intra16x16 luma DC on the un-halved 4x4 Hadamard output */
 VENC_DEV int venc_quant_luma_dc(int y, const venc_qparams *q) {
     return venc_quant_mag(y, q->mf[0], 4 * q->f_intra, q->qbits + 2);
 }
 VENC_DEV int venc_dequant_luma_dc(int f, const venc_qparams *q) {
     int ls = 16 * q->v[0];
-    if (q->per >= 6) return (f * ls) << (q->per - 6);
-    return (f * ls + (1 << (5 - q->per))) >> (6 - q->per);
+    /* |f| < 2^20 (Hadamard of 16 levels), ls <= 464 */
+    if (q->per >= 6) return VENC_MUL24(f, ls) << (q->per - 6);
+    return (VENC_MUL24(f, ls) + (1 << (5 - q->per))) >> (6 - q->per);
 }
 VENC_DEV int venc_quant_chroma_dc(int y, const venc_qparams *q, int intra) {
     return venc_quant_mag(y, q->mf[0], 2 * (intra ? q->f_intra : q->f_inter), q->qbits + 1);
 }
-VENC_DEV int venc_dequant_chroma_dc(int f, const venc_qparams *q) { return ((f * 16 * q->v[0]) << q->per) >> 5; }
+VENC_DEV int venc_dequant_chroma_dc(int f, const venc_qparams *q) { return (VENC_MUL24(f, 16 * q->v[0]) << q->per) >> 5; } /* |f| < 2^18 */
 
 /* ---------------------------------------------------------------- bit sink */
 /* MSB-first 32-bit words into lane-private memory */

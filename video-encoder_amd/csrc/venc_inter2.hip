@@ -25,7 +25,7 @@ DEVFN void blk_quant_recon(const int w[16], const venc_qparams &q, int f, int d0
         if (DC_SEP && i == 0) l = 0;
         lv[i] = l;
         nnz += (l != 0);
-        d[r] = (l * q.v[cls]) << q.per;
+        d[r] = VENC_MUL24(l, q.v[cls]) << q.per; /* |l| < 2^16, v <= 29 */
     }
     if (DC_SEP) d[0] = d0;
     int rr[16];
@@ -152,12 +152,18 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
 #pragma unroll
             for (int x = 0; x < 5; x++) smp[y][x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
     }
-    const int wa = (8 - xf) * (8 - yf), wb = xf * (8 - yf), wc = (8 - xf) * yf, wd = xf * yf;
+    /* 8.4.2.2.2 with fractions in {0, 4}: ((8-xf)(8-yf) A + xf (8-yf) B + (8-xf) yf C + xf yf D + 32) >> 6 is A, (A+B+1)>>1,
+     * (A+C+1)>>1 or (A+B+C+D+2)>>2 -- in every case (A + X + Y + Z + 2) >> 2 with X, Y, Z picked among A, B, C, D.  Three
+     * selects and four adds per sample instead of four quarter-rate 32-bit multiplies. */
+    const bool fx = xf != 0, fy = yf != 0;
 #pragma unroll
     for (int y = 0; y < 4; y++)
 #pragma unroll
-        for (int x = 0; x < 4; x++)
-            p[4 * y + x] = (wa * smp[y][x] + wb * smp[y][x + 1] + wc * smp[y + 1][x] + wd * smp[y + 1][x + 1] + 32) >> 6;
+        for (int x = 0; x < 4; x++) {
+            const int A = smp[y][x], Bv = smp[y][x + 1], Cv = smp[y + 1][x], Dv = smp[y + 1][x + 1];
+            const int X = fx ? Bv : A, Y = fy ? Cv : A, Z = fx ? (fy ? Dv : Bv) : (fy ? Cv : A);
+            p[4 * y + x] = (A + X + Y + Z + 2) >> 2;
+        }
 
     int res[16], w[16], lv[16], rr[16], nnz;
 #pragma unroll

@@ -329,7 +329,7 @@ DEVFN void mb_code(int lane, const int cur[16], const int pred[16], const venc_g
         if (i == 0 && dc_sep) l = 0;
         o.lv[i] = l;
         nnz += (l != 0);
-        d[r] = (l * vv) << per;
+        d[r] = VENC_MUL24(l, vv) << per;
     }
     if (dc_sep) d[0] = luma ? d0_luma : d0_chroma;
     o.dclv = luma ? dcl_luma : dcl_chroma;
