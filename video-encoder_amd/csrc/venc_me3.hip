@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ uint32_t s_best[T2_MBX * T2_MBY];
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
     __shared__ uint32_t s_total;
+    __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
     __shared__ __attribute__((aligned(4))) uint16_t s_rank[VENC_ME_CANDS + 1];
     uint2 *const s_h8 = (uint2 *)s_hv; /* T2_WR * T2_HG uint2 = 19968 B of the 30576 */
     uint4 *const s_v8 = s_hv;
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * tie-break ranks go to LDS ---- */
     const uint32_t *rank32 = (const uint32_t *)B.me_rank; /* 1089 u16 = 545 dwords (table padded by the launcher) */
     const uint32_t rk0 = rank32[tid], rk1 = tid + 512 < 545 ? rank32[tid + 512] : 0u;
-    const uint32_t prev = B.mvsad_prev[mbidx];
+    const uint32_t prev_early = B.mvsad_prev[mbidx]; /* issued with the other loads; parked in LDS until P4a */
     uint2 cu;
     {
         const int cy_ = min(y0 + (tid >> 4), g.h - 1), cx_ = x0 + (tid & 15) * 8;
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         ((uint32_t *)s_rank)[tid] = rk0;
         if (tid + 512 < 545) ((uint32_t *)s_rank)[tid + 512] = rk1;
         if (tid == 0) s_total = 0;
+        if (l32 == 0) s_prev[hw] = prev_early;
     }
     __syncthreads();
     if (S.me_stop == 1) return;
@@ -260,6 +262,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         if (l32 == 0) lmin = min(lmin, (lbx1 << 12) | (uint32_t)(32 * 33 + 32));
         ai = (int)(half_min32(lmin, lane) & 4095u);
     }
+    /* The lane's indices are derived again from an opaque copy of the thread id: the first copies die with P3, where
+     * the 33 bounds plus the sums in flight set the kernel's register peak (88 against the 80 that six waves per SIMD
+     * allow; capped by the compiler alone, the excess became 80 MB of scratch traffic per launch). */
+    {
+    int tid_b = threadIdx.x;
+    asm volatile("" : "+v"(tid_b));
+    const int tid = tid_b;
+    const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32, hw = tid >> 5;
+    const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
+    const int col0 = mbx * 16, row0 = mby * 16;
+    const int mx = tx * T2_MBX + mbx, my = S.row0 + ty * T2_MBY + mby;
+    const bool mb_valid = mx < g.mbw && my < S.row1;
+    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
+    const uint32_t prev = s_prev[hw];
     if (S.me_stop == 4) {
         if (l32 == 0 && mb_valid) B.mvsad[mbidx] = (uint32_t)ai << 16;
         return;
@@ -365,5 +381,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         B.me_flag[mbidx] = overflow ? 1 : 0; /* k_me_fix searches it exhaustively */
         if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(my * g.mbw + mx);
         B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
+    }
     }
 }
