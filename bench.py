@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip); 300 = the whole clip, ~15 s on 16 cores")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--mode", default="streams", choices=("streams", "slices"),
