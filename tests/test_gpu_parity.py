@@ -48,7 +48,7 @@ def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x
         # macroblock bit counts (the first MB of a slice also carries the slice header on the GPU)
         bits_g, bits_o = eng.debug(3).astype(np.int64), enc.mb_bits().astype(np.int64)
         first = set(int(r) * enc.mbw for r in enc.slice_rows()[:-1])
-        idx = np.array([i for i in range(enc.nmb) if i not in first])
+        idx = np.array([i for i in range(enc.nmb) if i not in first], dtype=np.int64)
         if not np.array_equal(bits_g[idx], bits_o[idx]):
             bad = idx[np.nonzero(bits_g[idx] != bits_o[idx])[0]]
             raise AssertionError("mb bits %s: first bad mb %d gpu %d orc %d (%d bad)" % (
@@ -70,6 +70,10 @@ def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x
     (178, 146, 30, 3, 3, 4, "noise"),      # not a multiple of 16 nor of 4: clamped ingest paths
     (640, 368, 38, 23, 2, 3, "synth"),     # chroma QP table region, many slices
     (1920, 1080, 26, 8, 2, 2, "synth"),    # BASELINE config 2 geometry
+    (3840, 2160, 26, 8, 2, 2, "synth"),    # BASELINE config 3 / 5 geometry
+    (16, 16, 30, 1, 2, 3, "noise"),        # one macroblock: every window piece but one lies outside the picture
+    (144, 32, 24, 2, 3, 4, "noise"),       # one tile row, second tile column partly outside
+    (130, 258, 36, 5, 3, 4, "noise"),      # 9 x 17 macroblocks: ragged right and bottom tiles, uneven slices
 ])
 def test_stages_match_oracle(venc, orc, w, h, qp, slices, keyint, n, kind):
     _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind)
@@ -340,3 +344,45 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
             assert dec.decode(b"".join(struct.pack(">I", len(x)) + x for x in sps + pps)) == 0
         assert dec.decode(got[k]) == 1
         assert np.array_equal(dec.planes()[0], enc.recon()[0])
+
+
+def test_baseline_config2_whole_clip_properties(venc, orc):
+    """BASELINE config 2 at full size (1920x1080, 300 frames, GOP 30, 8 slices, QP 26), where the oracle is too slow to
+    encode along: size-independent properties.  The lock-step schedule does not change the stream (10 GOPs at a time ==
+    3 at a time, a digest of all frame digests), every frame decodes with the oracle's decoder, decoded pictures stay
+    close to the input (PSNR) and the stream equals the one bench.py measures."""
+    import hashlib
+    import torch
+    w, h, n, keyint = 1920, 1080, 300, 30
+    fb = w * h * 3 // 2
+    buf = torch.empty(n * fb, dtype=torch.uint8, device="cuda")
+    assert venc.hip_lib().venc_synth_device(buf.data_ptr(), fb, w, h, 0, n, 0x1234ABCD) == 0
+    digests = []
+    for gb in (10, 3):
+        e = venc.X264Encoder(w, h, qp=26, slices=8, keyint=keyint, fps=(30, 1), sar=(1, 1), gop_batch=gb)
+        md, frames = hashlib.sha256(), []
+
+        def sink(payload, nals, pts, key, md=md, frames=frames):
+            md.update(hashlib.sha256(payload).digest())
+            frames.append((payload, pts, key))
+        assert e.encode_resident(buf.data_ptr(), fb, n, sink) == n
+        if gb == 10:
+            tally = e.encode_resident_tally(buf.data_ptr(), fb, n)
+            assert tally.frames == n and tally.keyframes == n // keyint
+            assert tally.bytes == sum(len(f[0]) for f in frames)
+        e.close()
+        digests.append(md.hexdigest())
+        if gb == 10:
+            kept = frames
+    assert digests[0] == digests[1]
+    assert [f[1] for f in kept] == list(range(n)) and [f[2] for f in kept] == [t % keyint == 0 for t in range(n)]
+    dec = orc.Decoder()
+    host = buf.cpu().numpy().reshape(n, fb)
+    worst = 99.0
+    for t, (payload, _, _) in enumerate(kept):
+        assert dec.decode(payload) == 1, "frame %d" % t
+        if t % 29 == 0:
+            y = dec.planes()[0][:h, :w].astype(np.float64)
+            mse = np.mean((y - host[t][:w * h].reshape(h, w)) ** 2)
+            worst = min(worst, 10 * np.log10(255.0 ** 2 / max(mse, 1e-9)))
+    assert worst > 33.0, worst
