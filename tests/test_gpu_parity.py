@@ -344,6 +344,15 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
             assert dec.decode(b"".join(struct.pack(">I", len(x)) + x for x in sps + pps)) == 0
         assert dec.decode(got[k]) == 1
         assert np.array_equal(dec.planes()[0], enc.recon()[0])
+    # the reference's own command line (av_encode.c:89-196): long options, "input output", --frame-limit enforced
+    mp4b = str(tmp_path / "ref_cli.mp4")
+    out = subprocess.check_output([tool, "--silent", "--frame-limit", "5", "--preset", "fast", "--tune", "zerolatency", "--quality", "27",
+                                   "--filters", "yadif", y4m, mp4b], stderr=subprocess.STDOUT).decode()
+    assert "frame_limit: 5" in out and "preset: fast" in out and "--filters belongs to" in out
+    tb = read_track(open(mp4b, "rb").read())
+    assert len(tb["stsz"]) == 5 and tb["stss"] == [1] and tb["timescale"] == 24  # default keyint 30: one GOP
+    assert subprocess.call([tool, "--preset", "warp9", y4m, mp4b], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 6
+    assert subprocess.call([tool, "--nonsense", y4m, mp4b], stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL) == 1
 
 
 def test_baseline_config2_whole_clip_properties(venc, orc):

@@ -23,14 +23,27 @@
  *
  * usage: encode_yuv [-s WxH] [-n frames] [-q qp] [-S slices] [-k keyint] [-g gop_batch] [-t tune]
  *                   [-i in.y4m|in.yuv] [-o out.h264] [-m out.mp4] [-f fps]
+ *
+ * The reference's own command line (av_encode.c:89-196) is accepted too, by
+ * its long option names -- its short ones (-s -d -l -f) collide with the switches above:
+ *        encode_yuv [--silent] [--debug] [--frame-limit N] [--preset P] [--tune T] [--quality Q]
+ *                   [--profile P] [--video-stream N] [--audio-stream N] [--filters F] input output
+ * input: .y4m (or headerless I420 with -s); output: .mp4 -> the MP4 writer, anything else -> Annex-B.
+ * --quality is the reference's CRF number (default 20, av_encode.c:104), mapped to the fixed QP by the
+ * shim; --frame-limit is enforced (the reference parses it and then ignores it); stream selection and
+ * filters belong to the libav* stages that are out of scope: accepted and ignored with a note.  Unless
+ * --silent (default when stdin is not a terminal, as in the reference) a progress line in the
+ * reference's format is printed every half second (av_encode.c:1032-1069, without the audio half).
  */
-#define _POSIX_C_SOURCE 200809L
+#define _GNU_SOURCE
+#include <getopt.h>
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "venc_hip.h"
 #include "venc_mp4.h"
@@ -199,7 +212,74 @@ static double now_s(void) {
 int main(int argc, char **argv) {
     int w = 0, h = 0, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 1, fps = 30, fps_den = 1, sar_num = 1, sar_den = 1;
     int fps_given = 0;
-    const char *in = NULL, *out = NULL, *mp4 = NULL, *tune = "film";
+    const char *in = NULL, *out = NULL, *mp4 = NULL, *tune = "film", *preset = "medium", *profile = NULL;
+    bool silent = !isatty(STDIN_FILENO), debug_show = false, ref_cli = false;
+    long long frame_limit = -1;
+    float quality = -1.0f;
+    /* first pass: the reference's long options (av_encode.c:110-124); they are removed from argv */
+    {
+        static const struct option long_opts[] = {{"silent", no_argument, NULL, 's'},          {"debug", no_argument, NULL, 'd'},
+                                                  {"video-stream", required_argument, NULL, 'v'}, {"audio-stream", required_argument, NULL, 'a'},
+                                                  {"frame-limit", required_argument, NULL, 'l'}, {"filters", required_argument, NULL, 'F'},
+                                                  {"preset", required_argument, NULL, 1},        {"tune", required_argument, NULL, 2},
+                                                  {"quality", required_argument, NULL, 3},       {"profile", required_argument, NULL, 4},
+                                                  {NULL, 0, NULL, 0}};
+        char *rest[64];
+        int nrest = 0;
+        rest[nrest++] = argv[0];
+        for (int i = 1; i < argc && nrest < 63; i++) {
+            const char *a = argv[i];
+            if (strncmp(a, "--", 2) != 0) {
+                rest[nrest++] = argv[i];
+                continue;
+            }
+            const struct option *o = NULL;
+            for (const struct option *q = long_opts; q->name; q++)
+                if (!strcmp(a + 2, q->name)) o = q;
+            if (!o) {
+                fprintf(stderr, "%s: unrecognized option '%s'\n", argv[0], a);
+                return 1;
+            }
+            const char *val = NULL;
+            if (o->has_arg == required_argument) {
+                if (i + 1 >= argc) {
+                    fprintf(stderr, "%s: option '%s' requires an argument\n", argv[0], a);
+                    return 1;
+                }
+                val = argv[++i];
+            }
+            ref_cli = true;
+            switch (o->val) {
+                case 's': silent = true; break;
+                case 'd': debug_show = true; break;
+                case 'l': frame_limit = strtoll(val, NULL, 10); break;
+                case 'v':
+                case 'a':
+                case 'F': fprintf(stderr, "note: --%s belongs to the demux/decode/filter stages, which are out of scope: ignored\n", o->name); break;
+                case 1: preset = val; break;
+                case 2: tune = val; break;
+                case 3: quality = strtof(val, NULL); break;
+                case 4: profile = val; break;
+            }
+        }
+        for (int i = 0; i < nrest; i++) argv[i] = rest[i];
+        argc = nrest;
+    }
+    /* the reference takes "input output" as positional arguments (av_encode.c:172-187) */
+    if (argc >= 3 && argv[argc - 2][0] != '-' && argv[argc - 1][0] != '-' && (argc == 3 || argv[argc - 3][0] != '-' || ref_cli)) {
+        bool pair = true;
+        if (argc > 3 && argv[argc - 3][0] == '-' && strlen(argv[argc - 3]) == 2 && strchr("snqSkgftiom", argv[argc - 3][1])) pair = false;
+        if (pair) {
+            in = argv[argc - 2];
+            const char *o = argv[argc - 1];
+            const size_t n = strlen(o);
+            if (n > 4 && !strcmp(o + n - 4, ".mp4")) mp4 = o; else out = o;
+            argc -= 2;
+            ref_cli = true;
+        }
+    }
+    if (ref_cli && quality < 0) quality = 20.0f; /* av_encode.c:104 */
+    if (ref_cli) frames = 0x7fffffff;             /* the whole input, or --frame-limit */
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i], *v = i + 1 < argc ? argv[i + 1] : NULL;
         if (!strcmp(a, "-s") && v && sscanf(v, "%dx%d", &w, &h) == 2) i++;
@@ -232,13 +312,26 @@ int main(int argc, char **argv) {
     }
     x264_context_t x264;
     memset(&x264, 0, sizeof(x264));
-    if (!enc_x264_open(w, h, fps, fps_den, sar_num, sar_den, "medium", tune, qp, NULL, slices, keyint, gop_batch, &x264)) return 6;
+    if (quality >= 0) qp = (int)(quality + 0.5f);
+    if (frame_limit >= 0 && frame_limit < frames) frames = (int)frame_limit;
+    if (ref_cli)
+        printf("silent: %d \ndebug: %d \ninput_file: %s \noutput_file: %s \nframe_limit: %lld \npreset: %s \ntune: %s \nquality: %f \nprofile: %s\n", silent,
+               debug_show, in ? in : "(synthetic)", mp4 ? mp4 : out ? out : "(none)", frame_limit, preset, tune, (double)qp, profile ? profile : "(null)");
+    if (!enc_x264_open(w, h, fps, fps_den, sar_num, sar_den, preset, tune, qp, profile, slices, keyint, gop_batch, &x264)) return 6;
     /* track time base = 1 / frame rate, as the reference's codec context has it (av_encode.c:638) */
     if (mp4 && !(g_mp4 = venc_mp4_open(mp4, w, h, fps_den, fps, sar_num, sar_den))) return 2;
 
     const double t0 = now_s();
+    double last_progress = t0;
     int64_t encoded_video_pts = 0;
     for (int f = 0; f < frames; f++) {
+        if (!silent && now_s() - last_progress > 0.5) { /* av_encode.c:1032-1069, video half */
+            const double secs = (double)encoded_video_pts * fps_den / fps;
+            const long long s = (long long)secs;
+            printf("\rvideo: %lld:%02lld:%02lld (frame %d) - %.1f frames/s", s / 3600, (s / 60) % 60, s % 60, f, f / (now_s() - t0));
+            if (debug_show) printf("\n"); else fflush(stdout);
+            last_progress = now_s();
+        }
         x264.pic_in.i_type = X264_TYPE_AUTO;
         x264.pic_in.i_pts = f;
         if (src) {
@@ -266,6 +359,7 @@ int main(int argc, char **argv) {
     enc_x264_close(&x264);
     if (g_out) fclose(g_out);
     if (g_mp4 && venc_mp4_close(g_mp4) != 0) g_violations++;
+    if (!silent) printf("\n");
     if (src) venc_source_close(src);
     printf("{\"frames\": %ld, \"sync_samples\": %ld, \"bytes\": %ld, \"last_pts\": %lld, \"seconds\": %.4f, \"mpixels_per_s\": %.2f, \"violations\": %ld}\n",
            g_samples, g_sync_samples, g_bytes, (long long)encoded_video_pts, dt, g_samples * (double)w * h / dt / 1e6, g_violations);
