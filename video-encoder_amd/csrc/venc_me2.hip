@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
  * clip) run side by side instead of dragging whole tiles along.  The four waves of a block split
  * the 33 vertical displacements (9 each, the last wave's tail is masked); lane = horizontal
  * displacement.  k_me_tile appended the macroblock indices to fix_list / fix_count. */
-#define FIX_BLOCKS 64
+#define FIX_BLOCKS 256 /* per item: one listed macroblock per block in all but pathological pictures (a block that loops costs the step a second search latency) */
 #define FIX_WD 13 /* window row: 48 bytes + 4 spare, in dwords */
 #define FIX_NDY 9
 

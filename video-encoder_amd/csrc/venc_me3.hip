@@ -174,38 +174,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __syncthreads();
     if (S.me_stop == 2) return;
     /* ---- P2: vertical 8-sums, stored as vertical pairs V(x,y) = S8(x,y) | S8(x,y+8) << 16 so that the bound of a
-     * candidate needs two dword reads (left and right 8x8 columns) and no repacking.  7 segments of 8 rows x 39
-     * column groups; a thread slides down 16 rows of block sums.  The pairs overwrite the horizontal sums: every
-     * thread holds its 16 sums in registers before the barrier, the stores come after it. */
+     * candidate needs two dword reads (left and right 8x8 columns) and no repacking.  6 segments of 9 rows x 78 column
+     * pairs = 468 busy threads (the first layout, 7 x 8 rows x 39 groups of four columns, kept 273 threads busy and
+     * three waves idle); a thread slides down 17 rows of block sums of its two columns.  The pairs overwrite the
+     * horizontal sums: every thread holds its sums in registers before the barrier, the stores come after it. */
     {
-        const bool act = tid < 7 * T2_HG;
-        const int seg = act ? tid / T2_HG : 0, q = act ? tid - seg * T2_HG : 0;
-        const int r0 = seg * 8;
-        uint2 sr[16];
+        const bool act = tid < 6 * 2 * T2_HG;
+        const int seg = act ? tid / (2 * T2_HG) : 0, q2 = act ? tid - seg * 2 * T2_HG : 0;
+        const int r0 = seg * 9;
+        uint32_t sr[17]; /* S8 of rows r0 .. r0 + 16, two columns as packed u16 */
         if (act) {
-            const uint2 *col = s_h8 + r0 * T2_HG + q;
-            uint2 acc = col[0];
+            const uint32_t *col = (const uint32_t *)s_h8 + r0 * 2 * T2_HG + q2;
+            uint32_t acc = col[0];
 #pragma unroll
-            for (int k = 1; k < 8; k++) acc = pk4_add(acc, col[k * T2_HG]);
+            for (int k = 1; k < 8; k++) acc += col[k * 2 * T2_HG];
             sr[0] = acc;
 #pragma unroll
-            for (int k = 1; k < 16; k++) {
-                if (r0 + k <= T2_VR + 7) acc = pk4_sub(pk4_add(acc, col[(k + 7) * T2_HG]), col[(k - 1) * T2_HG]);
+            for (int k = 1; k < 17; k++) {
+                if (r0 + k <= T2_VR + 7) acc = acc + col[(k + 7) * 2 * T2_HG] - col[(k - 1) * 2 * T2_HG]; /* h8 rows <= 63 */
                 sr[k] = acc;
             }
         }
         __syncthreads();
         if (act) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < 9; k++) {
                 if (r0 + k < T2_VR) {
-                    const uint2 lo = sr[k], hi = sr[k + 8];
-                    uint4 o;
-                    o.x = (lo.x & 0xffffu) | (hi.x << 16);
-                    o.y = (lo.x >> 16) | (hi.x & 0xffff0000u);
-                    o.z = (lo.y & 0xffffu) | (hi.y << 16);
-                    o.w = (lo.y >> 16) | (hi.y & 0xffff0000u);
-                    s_v8[(r0 + k) * T2_HG + q] = o;
+                    const uint32_t lo = sr[k], hi = sr[k + 8];
+                    *(uint2 *)((uint32_t *)s_v8 + ((r0 + k) * T2_HG) * 4 + q2 * 2) =
+                        make_uint2((lo & 0xffffu) | (hi << 16), (lo >> 16) | (hi & 0xffff0000u));
                 }
             }
         }
