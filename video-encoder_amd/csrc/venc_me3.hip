@@ -76,11 +76,6 @@ DEVFN uint32_t me3_quarter_sad(const uint32_t *s_win, const uint32_t *s_cur, int
     a += dpp_fetch<DPP_ROW_SHR(8), 0xf>(a, 0u);
     return a;
 }
-DEVFN uint32_t me3_quarter_bcast(uint32_t a, int lane) {
-    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), q1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 31);
-    const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47), q3 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
-    return lane < 16 ? q0 : lane < 32 ? q1 : lane < 48 ? q2 : q3;
-}
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_me_pool(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ __attribute__((aligned(16))) uint32_t s_win[T2_WR * T2_WD];
@@ -92,6 +87,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
     __shared__ uint32_t s_total;
     __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
+    __shared__ __attribute__((aligned(8))) uint32_t s_c8[T2_MBX * T2_MBY][2]; /* per macroblock: TL | BL << 16, TR | BR << 16 (8x8 sums of the current pixels) */
     __shared__ __attribute__((aligned(4))) uint16_t s_rank[VENC_ME_CANDS + 1];
     uint2 *const s_h8 = (uint2 *)s_hv; /* T2_WR * T2_HG uint2 = 19968 B of the 30576 */
     uint4 *const s_v8 = s_hv;
@@ -170,6 +166,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (q0 + k < T2_HG) s_h8[r * T2_HG + q0 + k] = pk4_add(h4[k], h4[k + 1]);
+        /* the four 8x8 sums of every current macroblock, for the bounds of P3: thread = (macroblock, left / right
+         * column of 8x8 blocks), 16 rows of 8 pixels each (done here, off P3's critical path, instead of seven
+         * cross-lane exchanges per half-wave there) */
+        if (tid < 2 * T2_MBX * T2_MBY) {
+            const int m = tid >> 1, half = tid & 1;
+            const uint32_t *cp = s_cur + ((m >> 3) * 16) * T3_CW + (m & (T2_MBX - 1)) * 4 + half * 2;
+            uint32_t top = 0, bot = 0;
+#pragma unroll
+            for (int y = 0; y < 8; y++) {
+                const uint2 a = *(const uint2 *)(cp + y * T3_CW), bq = *(const uint2 *)(cp + (y + 8) * T3_CW);
+                top = __builtin_amdgcn_sad_u8(a.y, 0u, __builtin_amdgcn_sad_u8(a.x, 0u, top));
+                bot = __builtin_amdgcn_sad_u8(bq.y, 0u, __builtin_amdgcn_sad_u8(bq.x, 0u, bot));
+            }
+            s_c8[m][half] = top | (bot << 16);
+        }
     }
     __syncthreads();
     if (S.me_stop == 2) return;
@@ -210,19 +221,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __syncthreads();
     if (S.me_stop == 3) return;
 
-    /* ---- block sums of the current macroblock's four 8x8 quadrants ---- */
-    uint32_t cleft, cright; /* (top, bottom) sums of the left / right 8x8 columns */
-    {
-        const uint2 cq = *(const uint2 *)(s_cur + (row0 + (l32 >> 1)) * T3_CW + (col0 >> 2) + (l32 & 1) * 2);
-        uint32_t part = __builtin_amdgcn_sad_u8(cq.x, 0u, 0u);
-        part = __builtin_amdgcn_sad_u8(cq.y, 0u, part);
-        part += (uint32_t)__shfl_xor((int)part, 2);
-        part += (uint32_t)__shfl_xor((int)part, 4);
-        part += (uint32_t)__shfl_xor((int)part, 8);
-        const uint32_t q00 = (uint32_t)__shfl((int)part, hbase | 0), q01 = (uint32_t)__shfl((int)part, hbase | 1);
-        const uint32_t q10 = (uint32_t)__shfl((int)part, hbase | 16), q11 = (uint32_t)__shfl((int)part, hbase | 17);
-        cleft = q00 | (q10 << 16), cright = q01 | (q11 << 16);
-    }
+    const uint2 c8 = *(const uint2 *)s_c8[hw];
+    const uint32_t cleft = c8.x, cright = c8.y; /* (top, bottom) sums of the left / right 8x8 columns */
 
     /* ---- P3: packed lower bounds pk = LB << 6 | cy; lane = window column cx = l32, one register per vertical
      * displacement: LB = |V_left - (TL,BL)| + |V_right - (TR,BR)|, two v_sad_u16 on packed u16 pairs ---- */
@@ -249,15 +249,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         if (l32 == 0) lbx1 = __builtin_amdgcn_sad_u16(colp[32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[32 * T2_SU], cleft, 0u));
     }
     /* candidate with the smallest bound (any of them on ties: start points only steer the pruning) */
-    int ai;
+    int ai, acx, acy; /* candidate with the smallest bound: index and window position */
     {
         uint32_t m = pk[0];
 #pragma unroll
         for (int cy = 1; cy < 33; cy += 2) m = min(min(m, pk[cy]), pk[cy + 1]);
-        uint32_t lmin = ((m >> 6) << 12) | ((m & 63u) * 33u + (uint32_t)l32); /* (LB << 12) | candidate index */
-        lmin = min(lmin, (lbx0 << 12) | (uint32_t)(l32 * 33 + 32));
-        if (l32 == 0) lmin = min(lmin, (lbx1 << 12) | (uint32_t)(32 * 33 + 32));
-        ai = (int)(half_min32(lmin, lane) & 4095u);
+        uint32_t lmin = ((m >> 6) << 12) | ((m & 63u) << 6) | (uint32_t)l32; /* LB << 12 | cy << 6 | cx */
+        lmin = min(lmin, (lbx0 << 12) | ((uint32_t)l32 << 6) | 32u);
+        if (l32 == 0) lmin = min(lmin, (lbx1 << 12) | (32u << 6) | 32u);
+        const uint32_t w = half_min32(lmin, lane);
+        acy = (int)((w >> 6) & 63u), acx = (int)(w & 63u);
+        ai = acy * 33 + acx;
     }
     /* The lane's indices are derived again from an opaque copy of the thread id: the first copies die with P3, where
      * the 33 bounds plus the sums in flight set the kernel's register peak (88 against the 80 that six waves per SIMD
@@ -284,13 +286,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     uint32_t thr;
     {
         const bool second = (lane & 16) != 0;
-        const int acy = ai / 33, acx = ai - acy * 33;
-        const uint32_t s1 = me3_quarter_bcast(me3_quarter_sad(s_win, s_cur, col0, row0, lane, second ? acx : pcx, second ? acy : pcy), lane);
-        uint32_t key = (s1 << 11) | rank[second ? ai : ci_p];
-        key = min(key, (uint32_t)__shfl_xor((int)key, 16)); /* both quarters of the macroblock */
-        thr = key >> 11;
+        const uint32_t rank_p = rank[ci_p], rank_a = rank[ai]; /* issued before the SAD, used after it */
+        const uint32_t a = me3_quarter_sad(s_win, s_cur, col0, row0, lane, second ? acx : pcx, second ? acy : pcy);
+        /* quarter totals sit in lanes 15 / 31 / 47 / 63: quarters 0, 1 belong to the wave's first macroblock (last
+         * frame's vector, smallest bound), quarters 2, 3 to its second -- no cross-lane exchange beyond the readlanes */
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), q1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 31);
+        const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47), q3 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
+        const uint32_t sad_p = lane < 32 ? q0 : q2, sad_a = lane < 32 ? q1 : q3;
+        thr = min(sad_p, sad_a);
         if (l32 == 0) {
-            s_best[hw] = key;
+            s_best[hw] = min((sad_p << 11) | rank_p, (sad_a << 11) | rank_a);
             s_ovf[hw] = 0;
         }
     }
