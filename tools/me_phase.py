@@ -16,7 +16,7 @@ for i in range(items):
 torch.cuda.synchronize()
 H = venc.hip_lib()
 import ctypes as C
-for stop in (1, 2, 3, 4, 5, 0):  # (VENC_ME=tile for the predecessor kernel)
+for stop in (1, 2, 3, 4, 6, 5, 0):  # 6 = after the start-point SADs, before the survivor scan  # (VENC_ME=tile for the predecessor kernel)
     os.environ["VENC_ME_STOP"] = str(stop)
     eng = venc.Engine(w, h, qp=26, n_slices=8, max_items=items, in_slots=0, out_slots=2 * items)
     eng.set_input(clip.data_ptr(), fb, items * steps)

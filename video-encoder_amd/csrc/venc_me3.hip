@@ -36,7 +36,7 @@
  * other chain's blocks off the CUs they hold.
  */
 
-#define T3_POOL 1024 /* survivor pool of a tile; entry = (LB << 15) | (macroblock << 11) | candidate */
+#define T3_POOL 1024 /* survivor pool of a tile = 8 wave segments of 2 x T3_CAP; entry = (LB << 15) | (macroblock << 11) | candidate */
 #define T3_CAP SEA_LIST /* survivors one macroblock may put into the pool (64); more: exhaustive search by k_me_fix */
 #define T3_CW 32                             /* current tile row stride in dwords: 128 pixels */
 
@@ -83,9 +83,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     /* horizontal sums (P1 -> P2), then, after a barrier, the vertical pairs built from them (P2 -> P3) */
     __shared__ __attribute__((aligned(16))) uint4 s_hv[T2_VR * T2_HG];
     __shared__ uint32_t s_pool[T3_POOL];
+    static_assert(8 * 2 * T3_CAP <= T3_POOL, "eight wave segments of two macroblocks each");
     __shared__ uint32_t s_best[T2_MBX * T2_MBY];
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
-    __shared__ uint32_t s_total;
+    __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[8]; /* entries in each wave's pool segment */
     __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
     __shared__ __attribute__((aligned(8))) uint32_t s_c8[T2_MBX * T2_MBY][2]; /* per macroblock: TL | BL << 16, TR | BR << 16 (8x8 sums of the current pixels) */
     __shared__ __attribute__((aligned(4))) uint16_t s_rank[VENC_ME_CANDS + 1];
@@ -145,7 +146,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         *(uint2 *)(s_cur + (tid >> 4) * T3_CW + (tid & 15) * 2) = cu;
         ((uint32_t *)s_rank)[tid] = rk0;
         if (tid + 512 < 545) ((uint32_t *)s_rank)[tid + 512] = rk1;
-        if (tid == 0) s_total = 0;
         if (l32 == 0) s_prev[hw] = prev_early;
     }
     __syncthreads();
@@ -299,36 +299,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             s_ovf[hw] = 0;
         }
     }
-    /* ---- survivors: bound <= best start SAD, appended to the tile's pool.  Compaction by wave ballots: a row of
-     * bounds rarely holds a survivor, so the common case is one compare and one scalar branch per row; a row with
-     * survivors costs the wave one LDS atomic.  A macroblock with more than T3_CAP survivors (or one that meets a full pool) is listed for the exhaustive search. ---- */
+    if (S.me_stop == 6) { /* diagnostic: start points done, scan not started */
+        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = thr << 16;
+        return;
+    }
+    /* ---- survivors: bound <= best start SAD, appended to the tile's pool.  Every wave owns a segment of the pool
+     * (2 macroblocks x T3_CAP entries) and compacts into it with wave ballots: no atomics, no pool-full case.  Rows are
+     * tested four at a time; most groups hold no survivor.  A macroblock with more than T3_CAP survivors is listed for
+     * the exhaustive search (k_me_fix). ---- */
     uint32_t mycnt = 0; /* survivors of this lane's macroblock besides the start points */
     {
         const int thrk = mb_valid ? (int)((thr << 6) | 63u) : -1; /* (pk < 2^22: the signed compare never passes -1) */
         const uint32_t tag = (uint32_t)hw << 11;
         const uint32_t lt = (1u << l32) - 1u;
+        uint32_t *seg = s_pool + (tid >> 6) * (2 * T3_CAP);
+        uint32_t wcnt = 0; /* entries in this wave's segment (wave-uniform) */
+        auto append = [&](bool keep, uint32_t entry) { /* wave-uniform call sites only */
+            const unsigned long long kb = __ballot(keep);
+            if (kb == 0ull) return;
+            const uint32_t hm = (uint32_t)(kb >> hbase);
+            const bool put = keep && mycnt + (uint32_t)__popc(hm & lt) < T3_CAP;
+            const unsigned long long pb = __ballot(put);
+            if (put) seg[wcnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = entry;
+            wcnt += (uint32_t)__popcll(pb);
+            mycnt += (uint32_t)__popc(hm);
+        };
 #pragma unroll
-        for (int cy = 0; cy < 33; cy++) {
-            const bool hit = (int)pk[cy] <= thrk;
-            if (__ballot(hit) != 0ull) {
-                /* the rare path: the empty asm keeps its arithmetic inside the branch (hoisted, the 33 copies of it
-                 * cost 60+ registers) */
-                uint32_t pv = pk[cy];
-                asm volatile("" : "+v"(pv));
-                const uint32_t ci = (pv & 63u) * 33u + (uint32_t)l32;
-                const bool keep = hit && ci != (uint32_t)ci_p && ci != (uint32_t)ai;
-                const uint32_t hm = (uint32_t)(__ballot(keep) >> hbase);
-                const bool put = keep && mycnt + (uint32_t)__popc(hm & lt) < T3_CAP;
-                const unsigned long long pb = __ballot(put);
-                mycnt += (uint32_t)__popc(hm);
-                if (pb != 0ull) {
-                    const int first = (int)__builtin_ctzll(pb);
-                    uint32_t base = 0;
-                    if (lane == first) base = atomicAdd(&s_total, (uint32_t)__popcll(pb));
-                    base = (uint32_t)__builtin_amdgcn_readlane((int)base, first);
-                    const uint32_t idx = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u));
-                    if (put && idx < T3_POOL) s_pool[idx] = ((pv >> 6) << 15) | tag | ci;
-                    if ((uint32_t)(__ballot(put && idx >= T3_POOL) >> hbase) != 0u) mycnt = T3_CAP + 1; /* pool full */
+        for (int g0 = 0; g0 < 33; g0 += 4) {
+            int gmin = (int)pk[g0];
+#pragma unroll
+            for (int j = 1; j < 4; j++)
+                if (g0 + j < 33) gmin = min(gmin, (int)pk[g0 + j]);
+            if (__ballot(gmin <= thrk) == 0ull) continue;
+#pragma unroll
+            for (int cy = g0; cy < (g0 + 4 < 33 ? g0 + 4 : 33); cy++) {
+                const bool hit = (int)pk[cy] <= thrk;
+                if (__ballot(hit) != 0ull) {
+                    /* the rare path: the empty asm keeps its arithmetic inside the branch (hoisted, the 33 copies of
+                     * it cost 60+ registers) */
+                    uint32_t pv = pk[cy];
+                    asm volatile("" : "+v"(pv));
+                    const uint32_t ci = (pv & 63u) * 33u + (uint32_t)l32;
+                    append(hit && ci != (uint32_t)ci_p && ci != (uint32_t)ai, ((pv >> 6) << 15) | tag | ci);
                 }
             }
         }
@@ -336,35 +348,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const bool hit0 = mb_valid && lbx0 <= thr, hit1 = mb_valid && lbx1 <= thr;
             if (__ballot(hit0 || hit1) != 0ull) {
                 const uint32_t ci0 = (uint32_t)(l32 * 33 + 32), ci1 = (uint32_t)(32 * 33 + 32);
-                const bool k0 = hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ai;
-                const bool k1 = hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ai;
-                const uint32_t hm0 = (uint32_t)(__ballot(k0) >> hbase), hm1 = (uint32_t)(__ballot(k1) >> hbase);
-                const uint32_t pos0 = mycnt + (uint32_t)__popc(hm0 & lt);
-                mycnt += (uint32_t)__popc(hm0);
-                const bool put0 = k0 && pos0 < T3_CAP, put1 = k1 && mycnt < T3_CAP;
-                mycnt += (uint32_t)__popc(hm1);
-                uint32_t i0 = 0, i1 = 0;
-                if (put0) i0 = atomicAdd(&s_total, 1u);
-                if (put1) i1 = atomicAdd(&s_total, 1u);
-                if (put0 && i0 < T3_POOL) s_pool[i0] = (lbx0 << 15) | tag | ci0;
-                if (put1 && i1 < T3_POOL) s_pool[i1] = (lbx1 << 15) | tag | ci1;
-                if ((uint32_t)(__ballot((put0 && i0 >= T3_POOL) || (put1 && i1 >= T3_POOL)) >> hbase) != 0u) mycnt = T3_CAP + 1;
+                append(hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ai, (lbx0 << 15) | tag | ci0);
+                append(hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ai, (lbx1 << 15) | tag | ci1);
             }
         }
         if (l32 == 0 && mycnt > T3_CAP) s_ovf[hw] = 1;
+        if (lane == 0) s_wcnt[tid >> 6] = wcnt;
     }
     __syncthreads();
     if (S.me_stop == 5) {
         if (l32 == 0 && mb_valid) B.mvsad[mbidx] = s_best[hw] << 5;
         return;
     }
-    /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves ---- */
+    /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves; survivor k of the tile is entry
+     * k - (entries of the earlier segments) of the segment it falls into ---- */
     {
-        const uint32_t total = min(s_total, (uint32_t)T3_POOL);
+        const uint4 wa = *(const uint4 *)&s_wcnt[0], wb = *(const uint4 *)&s_wcnt[4];
+        const uint32_t wc[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+        uint32_t pre[9]; /* pre[j] = entries of the segments before j */
+        pre[0] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) pre[j + 1] = pre[j] + wc[j];
+        const uint32_t total = pre[8];
         for (uint32_t k = (uint32_t)(tid >> 4); k < ((total + 31u) & ~31u); k += 32u) {
-            const uint32_t e = k < total ? s_pool[k] : 0xffffffffu;
+            uint32_t start = 0, sbase = 0; /* branch-free: the last segment whose first entry is <= k */
+#pragma unroll
+            for (int j = 1; j < 8; j++) {
+                const bool past = k >= pre[j];
+                start = past ? pre[j] : start;
+                sbase = past ? (uint32_t)(j * 2 * T3_CAP) : sbase;
+            }
+            const bool found = k < total;
+            const uint32_t e = found ? s_pool[sbase + (k - start)] : 0xffffffffu;
             const int ehw = (int)((e >> 11) & 15u), ci = (int)(e & 2047u);
-            bool need = k < total;
+            bool need = found;
             if (need) need = s_ovf[ehw] == 0u && (e >> 15) <= (s_best[ehw] >> 11);
             if (__ballot(need) == 0ull) continue;
             const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
