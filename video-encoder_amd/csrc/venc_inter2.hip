@@ -214,7 +214,7 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
  * exhaustively and transformed them, to hide k_me_fix's serial 13 us.  The search's registers
  * (or, capped, its spills in the shared prologue) cost the transform blocks more occupancy than
  * the hidden kernel was worth (74 us against 13 + 44 us). */
-__global__ __launch_bounds__(256) void k_inter_fused(venc_geom g, venc_bufs B, venc_step S, int n_luma) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_inter_fused(venc_geom g, venc_bufs B, venc_step S, int n_luma) {
     const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int bx = blockIdx.x;
     const uint32_t *mvs = B.mvsad + (size_t)item * g.nmb;
