@@ -415,13 +415,32 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
     }
     int sid = d->n_slices_seen++;
     int mb = first_mb, nmb = d->mbw * d->mbh, cs = d->cw / 2;
-    while (b->pos < end) {
+    int pending_skips = 0, need_run = 1; /* slice_data() of 7.3.4, CAVLC: mb_skip_run, that many P_Skip macroblocks,
+                                            then -- if more data follows -- one macroblock_layer() */
+    for (;;) {
+        int skip = 0;
+        if (st == 0) {
+            if (pending_skips > 0) {
+                skip = 1;
+                pending_skips--;
+            } else if (need_run) {
+                if (b->pos >= end) break;
+                pending_skips = (int)br_ue(b);
+                need_run = 0;
+                if (pending_skips > 0) {
+                    skip = 1;
+                    pending_skips--;
+                }
+            }
+            if (!skip) {
+                if (b->pos >= end) break; /* the slice ended with a run of skipped macroblocks */
+                need_run = 1;
+            }
+        } else if (b->pos >= end)
+            break;
         if (mb >= nmb) FAIL(d, "too many macroblocks in slice");
         int mx = mb % d->mbw, my = mb / d->mbw;
-        if (st == 0) {
-            if (br_ue(b) != 0) FAIL(d, "P_Skip unsupported by this decoder build");
-        }
-        int t = (int)br_ue(b);
+        int t = skip ? 0 : (int)br_ue(b);
         d->mb_slice[mb] = sid;
         int aL = mb_avail(d, mx - 1, my, sid), aT = mb_avail(d, mx, my - 1, sid);
         if (st == 2 || t >= 5) {
@@ -522,14 +541,24 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
                 px = aA ? ax : aB ? bx_ : cx, py = aA ? ay : aB ? by_ : cy;
             else
                 px = med3(ax, bx_, cx), py = med3(ay, by_, cy);
-            int mvx = br_se(b) + 4 * px, mvy = br_se(b) + 4 * py;
-            if ((mvx & 3) || (mvy & 3)) FAIL(d, "sub-pel mv unsupported");
+            int mvx, mvy, cbp = 0;
+            if (skip) {
+                /* P_Skip (8.4.1.1): the vector is zero when A or B is missing or has a zero vector (every coded
+                 * neighbour here is a P macroblock with refIdx 0), else the 16x16 median prediction; no residual */
+                if (!aA || !aB || (ax == 0 && ay == 0) || (bx_ == 0 && by_ == 0)) px = py = 0;
+                mvx = 4 * px, mvy = 4 * py;
+            } else {
+                mvx = br_se(b) + 4 * px, mvy = br_se(b) + 4 * py;
+                if ((mvx & 3) || (mvy & 3)) FAIL(d, "sub-pel mv unsupported");
+            }
             d->mv[2 * mb] = (int8_t)(mvx / 4);
             d->mv[2 * mb + 1] = (int8_t)(mvy / 4);
-            int code = (int)br_ue(b);
-            if (code > 47) FAIL(d, "bad cbp code");
-            int cbp = orc_golomb_to_inter_cbp[code];
-            if (cbp) qp += br_se(b);
+            if (!skip) {
+                int code = (int)br_ue(b);
+                if (code > 47) FAIL(d, "bad cbp code");
+                cbp = orc_golomb_to_inter_cbp[code];
+                if (cbp) qp += br_se(b);
+            }
             /* prediction with coordinate clamping */
             uint8_t predl[256], pred[2][64];
             int dx = mvx >> 2, dy = mvy >> 2;

@@ -805,13 +805,26 @@ static void write_mb_intra(orc_enc *e, bw_t *b, int mx, int my, int srow) {
             cavlc_block(b, lv + blk * 16 + 1, 15, luma_nc(e, mx, my, orc_blk_x[blk], orc_blk_y[blk], srow));
     write_chroma_residual(e, b, mx, my, srow, lv, cbpc);
 }
-static void write_mb_inter(orc_enc *e, bw_t *b, int mx, int my, int srow) {
+/* P_Skip (7.3.4, 8.4.1.1): a macroblock is skipped when it has no residual (cbp = 0) and its vector equals the vector a
+ * decoder infers for a skipped macroblock: zero if A or B is missing or has a zero vector, else the 16x16 median
+ * prediction.  (Every neighbour in a P slice of this encoder is a P macroblock with refIdx 0.) */
+static int mb_is_skip(const orc_enc *e, int mx, int my, int srow) {
+    int mb = my * e->mbw + mx;
+    if (e->mb_cbp[mb] != 0) return 0;
+    int sx = 0, sy = 0;
+    if (mx > 0 && my > srow) {
+        const int8_t *a = e->mv + 2 * (mb - 1), *bb = e->mv + 2 * (mb - e->mbw);
+        if (!((a[0] == 0 && a[1] == 0) || (bb[0] == 0 && bb[1] == 0))) predict_mv(e, mx, my, srow, &sx, &sy);
+    }
+    return e->mv[2 * mb] == sx && e->mv[2 * mb + 1] == sy;
+}
+static void write_mb_inter(orc_enc *e, bw_t *b, int mx, int my, int srow, int skip_run) {
     int mb = my * e->mbw + mx;
     const int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     int cbp = e->mb_cbp[mb], cbpc = cbp >> 4, cbpl = cbp & 15;
     int px, py;
     predict_mv(e, mx, my, srow, &px, &py);
-    bw_ue(b, 0); /* mb_skip_run */
+    bw_ue(b, (uint32_t)skip_run); /* mb_skip_run: P_Skip macroblocks since the previous coded one */
     bw_ue(b, 0); /* mb_type P_L0_16x16 */
     bw_se(b, 4 * (e->mv[2 * mb] - px));
     bw_se(b, 4 * (e->mv[2 * mb + 1] - py));
@@ -984,13 +997,21 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
         bw_t b;
         bw_init(&b, e->slice_buf[s], e->slice_cap);
         write_slice_header(e, &b, r0 * e->mbw, idr);
+        int skip_run = 0;
         for (int my = r0; my < r1; my++)
             for (int mx = 0; mx < e->mbw; mx++) {
                 uint64_t before = b.total_bits;
                 if (idr)
                     write_mb_intra(e, &b, mx, my, r0);
-                else
-                    write_mb_inter(e, &b, mx, my, r0);
+                else if (mb_is_skip(e, mx, my, r0)) {
+                    skip_run++;
+                    /* a slice that ends in skipped macroblocks carries their count as a last mb_skip_run; the bits
+                     * are booked on the last macroblock of the slice */
+                    if (my == r1 - 1 && mx == e->mbw - 1) bw_ue(&b, (uint32_t)skip_run);
+                } else {
+                    write_mb_inter(e, &b, mx, my, r0, skip_run);
+                    skip_run = 0;
+                }
                 e->mb_bits[my * e->mbw + mx] = (uint32_t)(b.total_bits - before);
             }
         bw_trailing(&b);

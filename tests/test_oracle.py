@@ -103,8 +103,12 @@ def test_flat_frame_known_bitstream_shape(orc):
     assert (enc.mb_bits() == 8).all()
     assert [n[0] for n in fr.nals] == [7, 8, 5]
     p = enc.encode(y, c, c)
-    # P_L0_16x16, mvd 0, cbp 0: skip_run 1 + mb_type 1 + mvd 1+1 + cbp ue(0) 1 = 5 bits
-    assert (enc.mb_bits() == 5).all() and [n[0] for n in p.nals] == [1]
+    # zero vector, no residual: all 12 macroblocks are P_Skip; the slice data is one mb_skip_run = ue(12) = 0001101,
+    # booked on the last macroblock
+    bits = enc.mb_bits()
+    assert (bits[:-1] == 0).all() and bits[-1] == 7 and [n[0] for n in p.nals] == [1]
+    nal = [b for (ty, _, b) in split_nals(p.data) if ty == 1][0]
+    assert len(nal) <= 4  # slice header + 7 bits + stop bit
     assert np.array_equal(enc.recon()[0], np.full((48, 64), 128, np.uint8))
 
 

@@ -12,6 +12,40 @@
  * dense blocks in every macroblock) stay on k_cavlc.
  */
 
+/* ================================================================== k_skip
+ * P_Skip decisions of a P picture (7.3.4), one lane per macroblock: no residual and the vector a decoder infers
+ * (mb_is_p_skip).  The result is a bit mask of CODED macroblocks, one 64-bit word per 64 macroblocks of the picture
+ * (wave ballot); k_cavlc_p derives mb_skip_run from it by looking backwards for the previous coded macroblock of the
+ * slice -- a count-leading-zeros per word, and whole rows of skipped macroblocks are a handful of words. */
+__global__ __launch_bounds__(256) void k_skip(venc_geom g, venc_bufs B, venc_step S) {
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const int base = (S.mb0 & ~63) + blockIdx.x * 256; /* words are aligned to multiples of 64 macroblocks of the picture */
+    const int mb = base + tid;
+    const bool in = mb >= S.mb0 && mb < S.mb1;
+    const int mbc = in ? mb : S.mb0;
+    const int mx = mbc % g.mbw, my = mbc / g.mbw;
+    const int srow = slice_first_row_of(g, my);
+    const venc_mbinfo *infos = B.mbinfo + (size_t)item * g.nmb;
+    const uint32_t rec = ((const uint32_t *)(infos + mbc))[6]; /* bytes 24..27: cbp, flags, cbpc, pad */
+    const int cbp = (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4);
+    const bool skip = in && mb_is_p_skip(g, B.mvsad + (size_t)item * g.nmb, mbc, mx, mx > 0, my > srow, cbp);
+    const unsigned long long coded = __ballot(in && !skip);
+    if ((tid & 63) == 0 && (mb >> 6) < (g.nmb + 63) / 64) B.codedmask[(size_t)item * ((g.nmb + 63) / 64) + (mb >> 6)] = coded;
+}
+
+/* P_Skip macroblocks directly before macroblock mb in its slice (first macroblock: `first`), from the coded-macroblock mask */
+DEVFN uint32_t skip_run_before(const unsigned long long *mask, int mb, int first) {
+    int w = mb >> 6;
+    unsigned long long m = mask[w] & ((1ull << (mb & 63)) - 1ull); /* coded macroblocks below mb in its word */
+    for (;;) {
+        if ((w << 6) < first) m &= ~((1ull << (first & 63)) - 1ull); /* (only the slice's first word can start before it) */
+        if (m) return (uint32_t)(mb - 1 - ((w << 6) + 63 - __builtin_clzll(m)));
+        if ((w << 6) <= first) return (uint32_t)(mb - first);
+        w--;
+        m = mask[w];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ uint32_t s_lv[256 * 9]; /* per lane: the 16 levels of the block being coded (+1 dword against bank conflicts) */
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
@@ -50,7 +84,21 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
     venc_bitsink bs;
     venc_bs_init(&bs, B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS);
     if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
-    emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp);
+    const unsigned long long *mask = B.codedmask + (size_t)item * ((g.nmb + 63) / 64);
+    const bool skipped = !((mask[mb >> 6] >> (mb & 63)) & 1ull); /* k_skip */
+    const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
+    if (skipped && mb != slice_last) { /* P_Skip: no syntax of its own */
+        B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)venc_bs_flush(&bs);
+        return;
+    }
+    const uint32_t run = skip_run_before(mask, mb, srow * g.mbw);
+    if (skipped) {
+        /* a slice that ends in skipped macroblocks carries their count as a last mb_skip_run */
+        venc_bs_ue(&bs, run + 1u);
+        B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)venc_bs_flush(&bs);
+        return;
+    }
+    emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp, run);
 
     /* residual, syntax order: luma blocks of the coded 8x8s, chroma DC, chroma AC */
     for (int slot = 0; slot < 27; slot++) {

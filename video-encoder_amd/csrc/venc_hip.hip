@@ -72,7 +72,6 @@ struct venc_ctx {
     int band_s0, band_s1; /* slices coded by this context (venc_set_band); whole picture by default */
     int slice_rows[VENC_MAX_SLICES + 1];
     int me_stop;
-    int cavlc_legacy; /* VENC_CAVLC=legacy: half-wave-per-macroblock k_cavlc for P pictures too */
     int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
     int me_mode;  /* 0 pool (default): k_me_pool, successive elimination with in-kernel sums, pooled survivors, three
                      blocks per CU; 3 tile: its predecessor k_me_tile; 1 plane: sums from k_refsum; 2 dense: exhaustive
@@ -151,6 +150,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.mbbits);
     (void)hipFree(c->b.mbnbits);
     (void)hipFree(c->b.mboff);
+    (void)hipFree(c->b.codedmask);
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
@@ -307,6 +307,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.mbbits, G * nmb * VENC_MB_WORDS * 4));
     OPEN_OK(hipMalloc(&b.mbnbits, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.codedmask, G * ((nmb + 63) / 64) * 8));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
     b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
     OPEN_OK(hipMalloc(&b.refsum, G * b.refsum_item * 4));
@@ -320,7 +321,6 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
     c->me_stop = getenv("VENC_ME_STOP") ? atoi(getenv("VENC_ME_STOP")) : 0;
-    c->cavlc_legacy = getenv("VENC_CAVLC") && !strcmp(getenv("VENC_CAVLC"), "legacy");
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
@@ -526,10 +526,12 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         HIP_OK(hipStreamWaitEvent(s2, c->ev_main[p], 0));
     }
     prof_begin(c, KID_CAVLC, s2);
-    if (is_idr || c->cavlc_legacy)
+    if (is_idr)
         hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
-    else
+    else {
+        hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
         hipLaunchKernelGGL(k_cavlc_p, dim3((band_mbs + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S);
+    }
     prof_end(c, s2);
     if (c->overlap) {
         HIP_OK(hipEventRecord(c->ev_side[rs], s2));

@@ -88,6 +88,7 @@ typedef struct {
     uint32_t *mbbits;
     uint32_t *mbnbits;
     uint32_t *mboff;
+    unsigned long long *codedmask; /* [G][(nmb + 63) / 64] P pictures: bit = macroblock is coded (not P_Skip), k_skip */
     const int *slice_first_row; /* n_slices + 1 */
     const uint8_t *row_slice;   /* mbh */
     const uint16_t *me_rank;    /* [33*33] candidate (dyi*33+dxi) -> rank */

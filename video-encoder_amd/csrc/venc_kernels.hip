@@ -681,12 +681,10 @@ DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int i
     venc_bs_ue(bs, 1); /* disable_deblocking_filter_idc */
 }
 
-/* mb_skip_run, mb_type, mvd (median prediction 8.4.1.3.1), coded_block_pattern, mb_qp_delta of a P_L0_16x16 macroblock */
-DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t *mvs, int mb, int mx, int my, bool aL, bool aT,
-                            int cbp) {
-    (void)my;
-    const uint32_t me = mvs[mb];
-    const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+/* 16x16 motion vector prediction (8.4.1.3.1) of macroblock mb from its neighbours A (left), B (top), C (top right, or D top
+ * left when C is missing); also reports whether A / B is missing or has a zero vector -- then the vector a decoder infers
+ * for a P_Skip macroblock is zero instead (8.4.1.1) */
+DEVFN void mv_predict(const venc_geom &g, const uint32_t *mvs, int mb, int mx, bool aL, bool aT, int &pxv, int &pyv, bool &skip_zero) {
     bool aA = aL, aB = aT, aC = aT && (mx + 1 < g.mbw);
     const bool aD = aT && mx > 0;
     int ax = 0, ay = 0, bxv = 0, byv = 0, cx = 0, cy = 0;
@@ -706,14 +704,36 @@ DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t
         aC = true;
         cx = (int)(int8_t)(m & 255u), cy = (int)(int8_t)((m >> 8) & 255u);
     }
-    int pxv, pyv;
+    skip_zero = !aL || !aT || (ax == 0 && ay == 0) || (bxv == 0 && byv == 0);
     if (!aB && !aC && aA)
         pxv = ax, pyv = ay;
     else if ((int)aA + (int)aB + (int)aC == 1)
         pxv = aA ? ax : aB ? bxv : cx, pyv = aA ? ay : aB ? byv : cy;
     else
         pxv = venc_median3(ax, bxv, cx), pyv = venc_median3(ay, byv, cy);
-    venc_bs_ue(bs, 0); /* mb_skip_run */
+}
+
+/* P_Skip (7.3.4): no residual and the vector a decoder would infer */
+DEVFN bool mb_is_p_skip(const venc_geom &g, const uint32_t *mvs, int mb, int mx, bool aL, bool aT, int cbp) {
+    if (cbp != 0) return false;
+    int pxv, pyv;
+    bool z;
+    mv_predict(g, mvs, mb, mx, aL, aT, pxv, pyv, z);
+    const uint32_t me = mvs[mb];
+    const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+    return z ? (dx == 0 && dy == 0) : (dx == pxv && dy == pyv);
+}
+
+/* mb_skip_run, mb_type, mvd, coded_block_pattern, mb_qp_delta of a P_L0_16x16 macroblock */
+DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t *mvs, int mb, int mx, int my, bool aL, bool aT,
+                            int cbp, uint32_t skip_run) {
+    (void)my;
+    const uint32_t me = mvs[mb];
+    const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+    int pxv, pyv;
+    bool z;
+    mv_predict(g, mvs, mb, mx, aL, aT, pxv, pyv, z);
+    venc_bs_ue(bs, skip_run); /* mb_skip_run: P_Skip macroblocks since the previous coded one */
     venc_bs_ue(bs, 0); /* mb_type P_L0_16x16 */
     venc_bs_se(bs, 4 * (dx - pxv));
     venc_bs_se(bs, 4 * (dy - pyv));
@@ -837,7 +857,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
             venc_bs_ue(&bs, 0);
             venc_bs_se(&bs, 0);
         } else {
-            emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp);
+            emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp, 0u); /* (P pictures are coded by k_cavlc_p) */
         }
     }
     const int nbits = venc_bs_flush(&bs);
