@@ -402,7 +402,8 @@ def test_p_skip_runs_match_oracle(venc, orc, kind):
     nmb_p = (n - 1) * enc.nmb
     if kind in ("flat", "static_noise"):
         assert skipped >= 0.85 * nmb_p  # (the I picture does not reconstruct its source exactly: some residual survives)
-        assert all(len(g.payload) < 64 for g in got[1:])
+        if kind == "flat":
+            assert all(len(g.payload) < 64 for g in got[1:])
     elif kind == "half_static":
         assert 0.3 * nmb_p < skipped < 0.6 * nmb_p
     else:

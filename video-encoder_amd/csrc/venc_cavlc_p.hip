@@ -1,16 +1,20 @@
 /*
- * venc_cavlc_p.hip -- entropy coding of P pictures with ONE LANE PER MACROBLOCK
+ * venc_cavlc_p.hip -- entropy coding of P pictures, ONE LANE PER SYNTAX UNIT of a macroblock
  * (SURVEY.md section 8a row a4.4).
  *
- * A P macroblock of typical content carries a handful of levels in one or two 4x4 blocks
- * (3-4 levels per coded macroblock on the synthetic clip).  k_cavlc gives every macroblock a
- * half-wave with one lane per block: 28 lanes for ~2 busy ones, plus prefix sums and an LDS
- * concatenation.  Here a lane walks its own macroblock in syntax order -- header, the coded luma
- * blocks, chroma DC, chroma AC -- and appends to its own bit string in HBM (the macroblock's
- * region of mbbits) through a 64-bit accumulator; no cross-lane step at all.  The wave's time is
- * the heaviest of its 64 macroblocks, which for P pictures is a few blocks.  I pictures (26
- * dense blocks in every macroblock) stay on k_cavlc.
+ * A macroblock of a P picture is cut into seven units that can be coded independently, because every CAVLC
+ * context (nC) comes from the TotalCoeff values the transform kernels already stored, not from coded bits:
+ *   unit 0  slice header (first macroblock of a slice), mb_skip_run .. mb_qp_delta, luma 8x8 block 0
+ *   unit 1-3  luma 8x8 blocks 1-3 (four 4x4 blocks each)        unit 4  Cb and Cr DC
+ *   unit 5  Cb AC (four blocks)                                 unit 6  Cr AC
+ * Eight lanes per macroblock (the eighth idles), each unit appends to its own 64-word bit string in the
+ * macroblock's region of mbbits; k_scan turns the seven lengths into offsets and k_pack gathers the strings.
+ * The first version gave a whole macroblock to one lane: a wave then took as long as the heaviest of its 64
+ * macroblocks -- up to 26 block codings, each behind a dependent load of its levels, ~100 us -- and the entropy
+ * chain became the longer of the two chains of a step.  A unit is at most four blocks.
+ * I pictures (26 dense blocks in every macroblock) stay on k_cavlc (one lane per block, LDS concatenation).
  */
+
 
 /* ================================================================== k_skip
  * P_Skip decisions of a P picture (7.3.4), one lane per macroblock: no residual and the vector a decoder infers
@@ -61,7 +65,8 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
               : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                         : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
-    const int mb_raw = S.mb0 + blockIdx.x * 256 + tid;
+    const int unit = tid & 7;
+    const int mb_raw = S.mb0 + blockIdx.x * 32 + (tid >> 3);
     const bool valid = mb_raw < S.mb1;
     const int mb = valid ? mb_raw : S.mb0;
     const int mx = mb % g.mbw, my = mb / g.mbw;
@@ -81,45 +86,49 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
     const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
     uint32_t *strip = s_lv + tid * 9;
     const int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
-    venc_bitsink bs;
-    venc_bs_init(&bs, B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS);
-    if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
+    uint16_t *ubits = B.ubits + ((size_t)item * g.nmb + mb) * 8;
     const unsigned long long *mask = B.codedmask + (size_t)item * ((g.nmb + 63) / 64);
     const bool skipped = !((mask[mb >> 6] >> (mb & 63)) & 1ull); /* k_skip */
-    const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
-    if (skipped && mb != slice_last) { /* P_Skip: no syntax of its own */
-        B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)venc_bs_flush(&bs);
-        return;
-    }
-    const uint32_t run = skip_run_before(mask, mb, srow * g.mbw);
-    if (skipped) {
-        /* a slice that ends in skipped macroblocks carries their count as a last mb_skip_run */
-        venc_bs_ue(&bs, run + 1u);
-        B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)venc_bs_flush(&bs);
-        return;
-    }
-    emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp, run);
+    venc_bitsink bs;
+    venc_bs_init(&bs, B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS + unit * VENC_UNIT_WORDS);
 
-    /* residual, syntax order: luma blocks of the coded 8x8s, chroma DC, chroma AC */
-    for (int slot = 0; slot < 27; slot++) {
-        if (slot == 16) continue; /* Intra16x16 DC: not in P macroblocks */
-        bool coded;
+    /* blocks of this unit: slots first_slot .. first_slot + n_slots - 1 of the level record */
+    int first_slot = 0, n_slots = 0;
+    if (unit < 4) {
+        first_slot = 4 * unit;
+        n_slots = (!skipped && ((cbpl >> unit) & 1)) ? 4 : 0;
+    } else if (unit == 4) {
+        first_slot = 17;
+        n_slots = (!skipped && cbpc > 0) ? 2 : 0;
+    } else if (unit < 7) {
+        first_slot = unit == 5 ? 19 : 23;
+        n_slots = (!skipped && cbpc == 2) ? 4 : 0;
+    }
+    if (unit == 0) {
+        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
+        const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
+        if (!skipped || mb == slice_last) {
+            const uint32_t run = skip_run_before(mask, mb, srow * g.mbw);
+            if (skipped)
+                venc_bs_ue(&bs, run + 1u); /* a slice that ends in skipped macroblocks carries their count as a last mb_skip_run */
+            else
+                emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp, run);
+        }
+    }
+    for (int k = 0; k < n_slots; k++) {
+        const int slot = first_slot + k;
         int first = 0, maxc = 16, nC = 0, own_idx = 0;
         bool has_nnz_entry = true;
         if (slot < 16) {
-            coded = (cbpl >> (slot >> 2)) & 1;
             own_idx = blk_y(slot) * 4 + blk_x(slot);
         } else if (slot < 19) {
-            coded = cbpc > 0;
             maxc = 4;
             nC = -1;
             has_nnz_entry = false;
         } else {
-            coded = cbpc == 2;
             first = 1, maxc = 15;
             own_idx = 16 + (slot - 19);
         }
-        if (!coded) continue;
         if (nC == 0) {
             int ia, ib;
             bool inA, inB;
@@ -158,6 +167,5 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
         }
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, first, maxc, nC, s_tab);
     }
-    const int nbits = venc_bs_flush(&bs);
-    B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)nbits;
+    ubits[unit] = (uint16_t)venc_bs_flush(&bs); /* the idle eighth lane writes 0 */
 }

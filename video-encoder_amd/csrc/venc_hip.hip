@@ -149,6 +149,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.mbinfo);
     (void)hipFree(c->b.mbbits);
     (void)hipFree(c->b.mbnbits);
+    (void)hipFree(c->b.ubits);
     (void)hipFree(c->b.mboff);
     (void)hipFree(c->b.codedmask);
     (void)hipFree(c->b.refsum);
@@ -306,6 +307,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMemset(b.mbinfo, 0, VENC_RING * G * nmb * sizeof(venc_mbinfo)));
     OPEN_OK(hipMalloc(&b.mbbits, G * nmb * VENC_MB_WORDS * 4));
     OPEN_OK(hipMalloc(&b.mbnbits, G * nmb * 4));
+    OPEN_OK(hipMalloc(&b.ubits, G * nmb * 8 * 2));
     OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.codedmask, G * ((nmb + 63) / 64) * 8));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
@@ -530,7 +532,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
     else {
         hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
-        hipLaunchKernelGGL(k_cavlc_p, dim3((band_mbs + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S);
+        hipLaunchKernelGGL(k_cavlc_p, dim3((band_mbs + 31) / 32, 1, n_items), dim3(256), 0, s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {

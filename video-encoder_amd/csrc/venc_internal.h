@@ -8,7 +8,7 @@
  *   mvsad         [G][nmb] u32   = sad<<16 | (dy&255)<<8 | (dx&255)
  *   levels        [G][nmb][27][16] i16   (block order documented in include/venc_hip.h)
  *   mbinfo        [G][nmb] 32 B  = nnz[24] (16 luma raster, 4 Cb, 4 Cr), cbp, flags
- *   mbbits        [G][nmb][VENC_MB_WORDS] u32  MSB-first macroblock bit strings
+ *   mbbits        [G][nmb][VENC_MB_WORDS] u32  MSB-first bit strings, one per syntax unit (unit u at word 64 u)
  *   mbnbits/mboff [G][nmb] u32
  *   refsum        [G][ch+25][cw+17 (padded)] u32 = S8(x,y) | S8(x+8,y)<<16 of the reference luma
  *   out (pinned host, device-mapped) [out_slots][out_cap] bytes + slice table
@@ -22,7 +22,8 @@
 #define VENC_MAX_ITEMS 64
 #define VENC_MAX_SLICES 256
 #define VENC_MB_COEFS 432   /* 27 blocks x 16 */
-#define VENC_MB_WORDS 416   /* per-macroblock bit-string capacity: 13312 bits */
+#define VENC_MB_WORDS 512   /* per-macroblock bit-string region: 8 units x 64 words (an I macroblock uses it as one string of <= 13312 bits) */
+#define VENC_UNIT_WORDS 64  /* P pictures: bit string of one syntax unit (at most four 4x4 blocks + the macroblock header: < 2048 bits) */
 #define VENC_LANE_WORDS 16  /* per-block private capacity: 512 bits >= 16 + 16*28 */
 #define VENC_ME_RANGE 16
 #define VENC_ME_CANDS 1089
@@ -87,6 +88,7 @@ typedef struct {
     venc_mbinfo *mbinfo;
     uint32_t *mbbits;
     uint32_t *mbnbits;
+    uint16_t *ubits;            /* [G][nmb][8] bits of the macroblock's syntax units (k_cavlc*), turned into running ends by k_scan */
     uint32_t *mboff;
     unsigned long long *codedmask; /* [G][(nmb + 63) / 64] P pictures: bit = macroblock is coded (not P_Skip), k_skip */
     const int *slice_first_row; /* n_slices + 1 */

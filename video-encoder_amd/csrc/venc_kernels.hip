@@ -864,7 +864,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     /* inclusive prefix over the 32 lanes of the team */
     int incl = (int)half_scan_incl32((uint32_t)nbits);
     int total = __shfl(incl, base | 31);
-    if (total > VENC_MB_WORDS * 32) total = VENC_MB_WORDS * 32; /* cannot happen for QP >= 12; keeps LDS in bounds */
+    if (total > 416 * 32) total = 416 * 32; /* cannot happen for QP >= 12; keeps LDS in bounds and the length inside 16 bits */
     const int off = incl - nbits;
     const int nw = (total + 31) >> 5;
     for (int j = l32; j < nw + 1; j += 32) s_mb[team][j] = 0;
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         const int myw = (nbits + 31) >> 5;
         for (int j = 0; j < myw; j++) {
             const int pos = off + 32 * j;
-            if (pos >= VENC_MB_WORDS * 32) break;
+            if (pos >= 416 * 32) break;
             const uint32_t wd = pw[j];
             const int shb = pos & 31;
             atomicOr(&s_mb[team][pos >> 5], wd >> shb);
@@ -885,7 +885,8 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     if (valid) {
         uint32_t *dst = B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS;
         for (int j = l32; j < nw; j += 32) dst[j] = s_mb[team][j];
-        if (l32 == 0) B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)total;
+        /* one string for the whole macroblock = unit 0 of the region (the other units are empty) */
+        if (l32 == 0) *(uint4 *)(B.ubits + ((size_t)item * g.nmb + mb) * 8) = make_uint4((uint32_t)total, 0u, 0u, 0u);
     }
 }
 
@@ -895,24 +896,39 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
 __global__ __launch_bounds__(1024) void k_scan(venc_geom g, venc_bufs B, venc_step S, venc_slice_out *slice_dev) {
     __shared__ uint32_t s_bits[VENC_MAX_SLICES];
     const int item = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
+    uint4 *ub = (uint4 *)(B.ubits + (size_t)item * g.nmb * 8); /* per macroblock: 8 x u16 unit lengths -> running ends */
+    uint32_t *nbp = B.mbnbits + (size_t)item * g.nmb;
     uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     /* one wave per slice (round-robin): 64 macroblocks per DPP scan, running total carried in a scalar */
     for (int s = S.slice0 + wv; s < S.slice1; s += 16) {
         const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
         uint32_t running = 0;
-        for (int c0 = first; c0 < last; c0 += 64 * 16) { /* 16 loads in flight per lane, then 16 register scans */
-            uint32_t v[16];
+        for (int c0 = first; c0 < last; c0 += 64 * 8) { /* 8 loads in flight per lane, then 8 register scans */
+            uint4 u[8];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 8; k++) {
                 const int i = c0 + 64 * k + lane;
-                v[k] = i < last ? nb[i] : 0u;
+                u[k] = i < last ? ub[i] : make_uint4(0, 0, 0, 0);
             }
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
+            for (int k = 0; k < 8; k++) {
                 const int i = c0 + 64 * k + lane;
-                const uint32_t incl = wave_scan_incl(v[k]);
-                if (i < last) offp[i] = running + incl - v[k];
+                /* lengths (l0 | l1 << 16, ...) -> running ends inside the macroblock; the last end is its total */
+                uint4 e;
+                e.x = u[k].x + (u[k].x << 16);
+                const uint32_t t1 = e.x >> 16;
+                e.y = u[k].y + (u[k].y << 16) + t1 * 0x00010001u;
+                const uint32_t t2 = e.y >> 16;
+                e.z = u[k].z + (u[k].z << 16) + t2 * 0x00010001u;
+                const uint32_t t3 = e.z >> 16;
+                e.w = u[k].w + (u[k].w << 16) + t3 * 0x00010001u;
+                const uint32_t v = e.w >> 16;
+                const uint32_t incl = wave_scan_incl(v);
+                if (i < last) {
+                    ub[i] = e;
+                    nbp[i] = v;
+                    offp[i] = running + incl - v;
+                }
                 running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             }
         }
@@ -948,30 +964,38 @@ DEVFN uint32_t fetch_bits(const uint32_t *wds, int pos, int n) { /* 1 <= n <= 32
 }
 
 #define PACK_MBS 256
+/* running end k (0..7) of a macroblock's units, from its 8 x u16 vector */
+DEVFN uint32_t unit_end(const uint4 &e, int k) {
+    const uint32_t w = k < 2 ? e.x : k < 4 ? e.y : k < 6 ? e.z : e.w;
+    return (k & 1) ? w >> 16 : w & 0xffffu;
+}
 /* One block per run of up to 256 consecutive macroblocks of a slice; consecutive lanes build
  * consecutive output words (coalesced stores towards the pinned host buffer).  The bit offsets of
- * the run sit in LDS; a word finds its first macroblock by binary search there. */
+ * the run and the unit ends of its macroblocks sit in LDS; a word finds its first macroblock by binary
+ * search there, the unit inside it by comparing against the seven ends (empty units vanish: their end
+ * equals their start). */
 __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_step S, const venc_slice_out *slice_dev) {
-    __shared__ uint32_t s_off[PACK_MBS], s_nb[PACK_MBS];
+    __shared__ uint32_t s_off[PACK_MBS];
+    __shared__ uint4 s_end[PACK_MBS];
     const int item = blockIdx.z, s = S.slice0 + blockIdx.y, tid = threadIdx.x;
     const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
     const int m0 = first + blockIdx.x * PACK_MBS;
     if (m0 >= last) return;
     const int n_here = min(PACK_MBS, last - m0);
     const venc_slice_out so = slice_dev[(size_t)item * g.n_slices + s];
-    const uint32_t *nb = B.mbnbits + (size_t)item * g.nmb;
+    const uint4 *endp = (const uint4 *)(B.ubits + (size_t)item * g.nmb * 8);
     const uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     const uint32_t *bits = B.mbbits + (size_t)item * g.nmb * VENC_MB_WORDS;
     uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
     uint32_t *out = (uint32_t *)(slot + B.out_data_off + so.byte_off);
     if (tid < n_here) {
         s_off[tid] = offp[m0 + tid];
-        s_nb[tid] = nb[m0 + tid];
+        s_end[tid] = endp[m0 + tid];
     }
     __syncthreads();
     const uint32_t T = so.nbits;
     const uint32_t begin = s_off[0];
-    const uint32_t end = (m0 + n_here == last) ? so.nbytes * 8u : s_off[n_here - 1] + s_nb[n_here - 1];
+    const uint32_t end = (m0 + n_here == last) ? so.nbytes * 8u : s_off[n_here - 1] + (s_end[n_here - 1].w >> 16);
     for (uint32_t w = ((begin + 31u) >> 5) + (uint32_t)tid; 32u * w < end; w += 256u) {
         if (so.byte_off + 4u * (w + 1u) > B.out_cap) break;
         uint32_t pos = 32u * w, val = 0;
@@ -985,23 +1009,27 @@ __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_ste
         }
         int got = 0, m = lo;
         while (got < 32 && m0 + m < last) {
-            uint32_t mo, mn;
+            uint32_t mo;
+            uint4 e;
             if (m < n_here)
-                mo = s_off[m], mn = s_nb[m];
+                mo = s_off[m], e = s_end[m];
             else
-                mo = offp[m0 + m], mn = nb[m0 + m]; /* the word runs on into the next block's macroblocks */
+                mo = offp[m0 + m], e = endp[m0 + m]; /* the word runs on into the next block's macroblocks */
             const uint32_t local = pos - mo;
-            if (local >= mn) {
+            if (local >= (e.w >> 16)) { /* past this macroblock's last bit */
                 m++;
                 continue;
             }
-            uint32_t take = mn - local;
+            int u = 0; /* unit that holds bit `local`: the first whose end lies beyond it */
+#pragma unroll
+            for (int k = 0; k < 7; k++) u += (int)(unit_end(e, k) <= local);
+            const uint32_t ustart = u ? unit_end(e, u - 1) : 0u;
+            uint32_t take = unit_end(e, u) - local;
             if (take > (uint32_t)(32 - got)) take = (uint32_t)(32 - got);
-            const uint32_t v = fetch_bits(bits + (size_t)(m0 + m) * VENC_MB_WORDS, (int)local, (int)take);
+            const uint32_t v = fetch_bits(bits + (size_t)(m0 + m) * VENC_MB_WORDS + u * VENC_UNIT_WORDS, (int)(local - ustart), (int)take);
             val = take == 32 ? v : ((val << take) | v);
             got += (int)take;
             pos += take;
-            if (local + take == mn) m++;
         }
         if (got < 32) {
             if (pos == T) { /* rbsp_stop_one_bit */
