@@ -263,7 +263,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     memcpy(c->slice_rows, rows, sizeof(int) * (g.n_slices + 1));
     c->band_s0 = 0;
     c->band_s1 = g.n_slices;
-    c->intra_waves = maxrows < INTRA_MAX_WAVES ? maxrows : INTRA_MAX_WAVES;
+    c->intra_waves = (maxrows + 1) / 2 < INTRA_MAX_WAVES ? (maxrows + 1) / 2 : INTRA_MAX_WAVES; /* two MB rows per wave */
     c->max_slice_mbs = maxrows * g.mbw;
     OPEN_OK(hipMalloc(&c->d_slice_rows, sizeof(int) * (g.n_slices + 1)));
     OPEN_OK(hipMemcpy(c->d_slice_rows, rows, sizeof(int) * (g.n_slices + 1), hipMemcpyHostToDevice));

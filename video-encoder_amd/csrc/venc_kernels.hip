@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
 /* ================================================================== k_intra
  * Intra16x16 with DC prediction needs the reconstructed left and top
  * neighbours, so a slice is a 2-D dependency wavefront.  One block per slice;
- * wave r owns MB row r of the band and runs one macroblock behind wave r-1.
+ * half-wave r owns MB row r of the band and runs one macroblock behind half-wave r-1.
  * Only the neighbour *sums* are needed for DC prediction, so waves hand over
  * five integers per macroblock through a small LDS ring. */
 #define INTRA_MAX_WAVES 16
@@ -516,10 +516,13 @@ DEVFN void load_cur_rows(const uint8_t *cur, int cstride, int pw, int ph, int px
 }
 
 __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ int s_bot[INTRA_MAX_WAVES][4][5];
+    __shared__ int s_bot[2 * INTRA_MAX_WAVES][4][5];
     const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
     const int nw = blockDim.x >> 6;
-    const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31;
+    const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
+    /* a macroblock needs 24 lanes: each HALF of a wave owns a macroblock row of the band (row wv and row wv + nw),
+     * so a block of 16 waves sweeps 32 rows in one pass (the 17-row slices of 2160p took two passes of 16 + 1) */
+    const int rw = wv + nw * (lane >> 5);
     const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
     const bool luma = l32 < 16;
     const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
@@ -530,9 +533,9 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
     uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
 
-    for (int cb = r0; cb < r1; cb += nw) {
-        const int nr = min(nw, r1 - cb);
-        const int my = cb + wv;
+    for (int cb = r0; cb < r1; cb += 2 * nw) {
+        const int nr = min(2 * nw, r1 - cb);
+        const int my = cb + rw;
         const int steps = g.mbw + nr - 1;
         int leftY = 0, leftC0 = 0, leftC1 = 0; /* per lane: sums relevant to this lane's plane */
         /* the current block's pixels are fetched one macroblock ahead so that the load latency
@@ -540,10 +543,10 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
         const bool cur_al = luma ? ((g.w & 3) == 0) : ((g.w & 7) == 0);
         const int pyl = (luma ? my * 16 : my * 8) + by;
         uint32_t cq[4] = {0, 0, 0, 0};
-        if (wv < nr) load_cur_rows(cur, cstride, pw, ph, bx, pyl, cur_al, cq);
+        if (rw < nr) load_cur_rows(cur, cstride, pw, ph, bx, pyl, cur_al, cq);
         for (int step = 0; step < steps; step++) {
-            const int mx = step - wv;
-            if (wv < nr && mx >= 0 && mx < g.mbw) {
+            const int mx = step - rw;
+            if (rw < nr && mx >= 0 && mx < g.mbw) {
                 uint32_t nq[4] = {0, 0, 0, 0};
                 if (mx + 1 < g.mbw) load_cur_rows(cur, cstride, pw, ph, (luma ? (mx + 1) * 16 : (mx + 1) * 8) + bx, pyl, cur_al, nq);
                 const int mb = my * g.mbw + mx;
@@ -551,8 +554,8 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                 /* top sums: [0] luma, [1],[2] Cb halves, [3],[4] Cr halves */
                 int t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
                 if (aT) {
-                    if (wv > 0) {
-                        const int *sb = s_bot[wv - 1][mx & 3];
+                    if (rw > 0) {
+                        const int *sb = s_bot[rw - 1][mx & 3];
                         t0 = sb[0], t1 = sb[1], t2 = sb[2], t3 = sb[3], t4 = sb[4];
                     } else {
                         /* row above belongs to the previous chunk of this slice: re-read its bottom lines */
@@ -591,7 +594,7 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
 
                 int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
                 venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
-                const bool st = lane < 32;
+                const bool st = true; /* both halves of the wave carry a macroblock */
                 mb_store(l32, st, o, lv_mb, info, rec, wstride, px, py);
                 /* luma DC record (slot 16, zig-zag order) and chroma DC records */
                 if (st && luma) {
@@ -602,15 +605,15 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                         if (venc_zigzag_ct(i) == rp) zi = i;
                     lv_mb[16 * 16 + zi] = (int16_t)o.dclv;
                 }
-                int dc0 = __shfl(o.dclv, (l32 & 28) | 0), dc1 = __shfl(o.dclv, (l32 & 28) | 1);
-                int dc2 = __shfl(o.dclv, (l32 & 28) | 2), dc3 = __shfl(o.dclv, (l32 & 28) | 3);
+                int dc0 = __shfl(o.dclv, hbase | (l32 & 28) | 0), dc1 = __shfl(o.dclv, hbase | (l32 & 28) | 1);
+                int dc2 = __shfl(o.dclv, hbase | (l32 & 28) | 2), dc3 = __shfl(o.dclv, hbase | (l32 & 28) | 3);
                 if (st && (l32 == 16 || l32 == 20)) {
                     uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
                     dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16),
                                         ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
                 }
-                const uint32_t hnz = (uint32_t)__ballot(o.nnz > 0), hdc = (uint32_t)__ballot(o.dclv != 0);
-                if (lane == 0) {
+                const uint32_t hnz = (uint32_t)(__ballot(o.nnz > 0) >> hbase), hdc = (uint32_t)(__ballot(o.dclv != 0) >> hbase);
+                if (l32 == 0) {
                     int cbpl = (hnz & 0xffffu) ? 15 : 0;
                     int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
                     info->cbp = (uint8_t)cbpl;
@@ -621,15 +624,15 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                 /* neighbour sums for the next macroblocks */
                 const int pb = o.rec[12] + o.rec[13] + o.rec[14] + o.rec[15];
                 const int pr = o.rec[3] + o.rec[7] + o.rec[11] + o.rec[15];
-                const int botY = __shfl(pb, 10) + __shfl(pb, 11) + __shfl(pb, 14) + __shfl(pb, 15);
-                const int rightY = __shfl(pr, 5) + __shfl(pr, 7) + __shfl(pr, 13) + __shfl(pr, 15);
-                const int bcb0 = __shfl(pb, 18), bcb1 = __shfl(pb, 19), bcr0 = __shfl(pb, 22), bcr1 = __shfl(pb, 23);
-                const int rcb0 = __shfl(pr, 17), rcb1 = __shfl(pr, 19), rcr0 = __shfl(pr, 21), rcr1 = __shfl(pr, 23);
+                const int botY = __shfl(pb, hbase | 10) + __shfl(pb, hbase | 11) + __shfl(pb, hbase | 14) + __shfl(pb, hbase | 15);
+                const int rightY = __shfl(pr, hbase | 5) + __shfl(pr, hbase | 7) + __shfl(pr, hbase | 13) + __shfl(pr, hbase | 15);
+                const int bcb0 = __shfl(pb, hbase | 18), bcb1 = __shfl(pb, hbase | 19), bcr0 = __shfl(pb, hbase | 22), bcr1 = __shfl(pb, hbase | 23);
+                const int rcb0 = __shfl(pr, hbase | 17), rcb1 = __shfl(pr, hbase | 19), rcr0 = __shfl(pr, hbase | 21), rcr1 = __shfl(pr, hbase | 23);
                 leftY = rightY;
                 leftC0 = plane == 2 ? rcr0 : rcb0;
                 leftC1 = plane == 2 ? rcr1 : rcb1;
-                if (lane == 0) {
-                    int *sb = s_bot[wv][mx & 3];
+                if (l32 == 0) {
+                    int *sb = s_bot[rw][mx & 3];
                     sb[0] = botY, sb[1] = bcb0, sb[2] = bcb1, sb[3] = bcr0, sb[4] = bcr1;
                 }
             }
