@@ -74,6 +74,7 @@ def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x
     (16, 16, 30, 1, 2, 3, "noise"),        # one macroblock: every window piece but one lies outside the picture
     (144, 32, 24, 2, 3, 4, "noise"),       # one tile row, second tile column partly outside
     (130, 258, 36, 5, 3, 4, "noise"),      # 9 x 17 macroblocks: ragged right and bottom tiles, uneven slices
+    (176, 464, 28, 1, 2, 3, "noise"),      # 29 MB rows in one slice: two passes of the intra DC chain (24 + 5 rows)
 ])
 def test_stages_match_oracle(venc, orc, w, h, qp, slices, keyint, n, kind):
     _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind)

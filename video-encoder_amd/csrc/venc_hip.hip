@@ -22,6 +22,7 @@
 #include "venc_me3.hip"
 #include "venc_inter2.hip"
 #include "venc_cavlc_p.hip"
+#include "venc_intra2.hip"
 #include "venc_synth.h"
 
 static thread_local char g_err[512] = "";
@@ -67,6 +68,8 @@ struct venc_ctx {
     uint8_t *d_row_slice;
     uint16_t *d_rank, *d_cand;
     int intra_waves;
+    int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
+    int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
     int max_slice_mbs;
     int steps_done;
     int band_s0, band_s1; /* slices coded by this context (venc_set_band); whole picture by default */
@@ -157,6 +160,8 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.me_cnt);
     (void)hipFree(c->b.stamps);
     (void)hipFree(c->b.fix_count);
+    (void)hipFree(c->b.intra_rec);
+    (void)hipFree(c->b.intra_d0);
     (void)hipFree(c->b.fix_list);
     (void)hipFree(c->d_slice);
     (void)hipFree(c->d_slice_rows);
@@ -263,6 +268,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     memcpy(c->slice_rows, rows, sizeof(int) * (g.n_slices + 1));
     c->band_s0 = 0;
     c->band_s1 = g.n_slices;
+    c->intra_cw = (maxrows + 1) / 2 < INTRA_CW_MAX ? (maxrows + 1) / 2 : INTRA_CW_MAX; /* compute waves of k_intra_dc */
+    {
+        const char *e = getenv("VENC_INTRA");
+        c->intra_legacy = e && !strcmp(e, "legacy");
+    }
     c->intra_waves = (maxrows + 1) / 2 < INTRA_MAX_WAVES ? (maxrows + 1) / 2 : INTRA_MAX_WAVES; /* two MB rows per wave */
     c->max_slice_mbs = maxrows * g.mbw;
     OPEN_OK(hipMalloc(&c->d_slice_rows, sizeof(int) * (g.n_slices + 1)));
@@ -327,6 +337,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
     OPEN_OK(hipMalloc(&b.fix_count, G * 4));
+    OPEN_OK(hipMalloc(&b.intra_rec, G * nmb * INTRA_REC_DWORDS * 4));
+    OPEN_OK(hipMalloc(&b.intra_d0, G * nmb * 32 * 4));
     OPEN_OK(hipMemset(b.fix_count, 0, G * 4));
     OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
@@ -481,7 +493,14 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     }
     if (is_idr) {
         prof_begin(c, KID_INTRA, s1);
-        hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
+        if (c->intra_legacy)
+            hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
+        else {
+            /* transform off the dependency chain, DC chain, reconstruction (venc_intra2.hip) */
+            hipLaunchKernelGGL(k_intra_fwd, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_intra_dc, dim3(band_slices, 1, n_items), dim3(1024), 0, s1, g, b, S, c->intra_cw);
+            hipLaunchKernelGGL(k_intra_rec, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
+        }
         prof_end(c, s1);
     } else {
         /* fix_count is zero here: zeroed at open and by k_inter_fused once k_me_fix has consumed it; the legacy
@@ -721,6 +740,8 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         case 9: src = c->b.me_cnt + item * nmb, n = nmb; break;
         case 11: src = c->b.stamps, n = 8 * sizeof(unsigned long long); break;
         case 10: src = c->b.me_flag + item * nmb, n = nmb; break;
+        case 12: src = c->b.intra_d0 + item * nmb * 32, n = nmb * 32 * 4; break;
+        case 13: src = c->b.intra_rec + item * nmb * INTRA_REC_DWORDS, n = nmb * INTRA_REC_DWORDS * 4; break;
         case 8: src = c->b.refsum + item * c->b.refsum_item, n = c->b.refsum_item * 4; break;
         default: SET_ERR("venc_debug_read: unknown selector %d", what); return -1;
     }

@@ -98,6 +98,8 @@ typedef struct {
     uint32_t *refsum;           /* [G][p8 rows][refsum_stride] packed 8x8 block sums of the reference (venc_me.hip) */
     int refsum_stride;          /* dwords per row */
     size_t refsum_item;         /* dwords per item */
+    int *intra_rec;             /* [G][nmb][128] I pictures: block DCs + un-rounded edge samples (k_intra_fwd -> k_intra_dc) */
+    int *intra_d0;              /* [G][nmb][32] I pictures: d0 + 64 pred + 32 per block (k_intra_dc -> k_intra_rec) */
     uint8_t *me_flag;           /* [G][nmb] 1 = k_me_tile left this macroblock to k_me_fix */
     uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zero at open; re-zeroed by k_inter_fused after k_me_fix) */
     uint32_t *fix_list;         /* [G][nmb] their indices */

@@ -1,0 +1,369 @@
+/*
+ * venc_intra2.hip -- I pictures (Intra16x16, DC prediction) as three kernels instead of one
+ * dependency wavefront that carried the whole transform (k_intra, venc_kernels.hip: ~1400
+ * instructions per macroblock step, ~4 us per step, 0.5 ms per I picture at 1080p).
+ *
+ * DC prediction makes the predictor a constant p per 4x4 block, and both transforms are linear:
+ *
+ *   forward:  T(cur - p) = T(cur) - p * T(1), and T(1) is 16 at position (0,0), zero elsewhere.
+ *             Every AC coefficient -- hence every AC level, every nnz, the luma part of
+ *             coded_block_pattern -- is independent of the neighbours.  Only W[0] = sum(cur) - 16 p
+ *             depends on them.
+ *   inverse:  the (0,0) coefficient d0 enters every output sample of venc_idct4 with weight 1 and
+ *             passes none of its ">> 1" terms, so  rec = clip(p + ((h + d0 + 32) >> 6))
+ *             = clip((h + d0 + 64 p + 32) >> 6),  h = the un-rounded inverse transform of the AC part.
+ *
+ * So the only work that has to walk the 2-D dependency wavefront is, per macroblock: the DC
+ * predictor, the 4x4 (luma) and 2x2 (chroma) Hadamard of the 24 block DCs, their quantisation and
+ * dequantisation, and the reconstruction of the 61 edge samples whose sums feed the neighbours.
+ *
+ *   k_intra_fwd   parallel over macroblocks: forward transform of the source, AC levels, nnz, the
+ *                 un-rounded inverse of the AC part for the edge samples -> a 512-byte record per MB
+ *   k_intra_dc    one block per slice, half-wave per MB row (as k_intra): the DC chain, ~150
+ *                 instructions per step.  The compute waves issue no global loads: the remaining
+ *                 waves of the block copy the records two steps ahead into an LDS ring, so no
+ *                 s_waitcnt vmcnt ever sits on the chain, and the step barrier is LDS-only.
+ *   k_intra_rec   parallel: inverse transform with d0 + 64 p in position 0, reconstruction.
+ *
+ * Results are bit-identical to k_intra (kept as VENC_INTRA=legacy and as the test oracle on the GPU).
+ * Follows spec/CODEC.md sections "Intra prediction" and "Transform and quantisation".
+ */
+#define INTRA_CW_MAX 12       /* compute waves per block: 24 MB rows per pass */
+#define INTRA_REC_DWORDS 128  /* per-macroblock record: [0..23] block DCs, [24 + 8 e ..] edge samples of edge block e */
+#define INTRA_MAX_MBW 1024
+
+/* edge blocks (right column or bottom row of their plane inside the macroblock) in lane order:
+ * luma 5 7 10 11 13 14 15, Cb 1 2 3, Cr 1 2 3 */
+DEVFN int intra_edge_slot(int l32) {
+    if (l32 < 16) {
+        const bool e = blk_x(l32) == 3 || blk_y(l32) == 3;
+        /* rank among {5,7,10,11,13,14,15} */
+        return e ? __popc(0xECA0u & ((1u << l32) - 1u)) : -1;
+    }
+    if (l32 < 24) {
+        const int k = l32 & 3;
+        return k ? 7 + 3 * ((l32 - 16) >> 2) + (k - 1) : -1;
+    }
+    return -1;
+}
+
+/* venc_idct4 without the final (x + 32) >> 6 */
+DEVFN void intra_idct4_raw(const int d[16], int h[16]) {
+    int f[16];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int e0 = d[4 * i] + d[4 * i + 2], e1 = d[4 * i] - d[4 * i + 2];
+        int e2 = (d[4 * i + 1] >> 1) - d[4 * i + 3], e3 = d[4 * i + 1] + (d[4 * i + 3] >> 1);
+        f[4 * i] = e0 + e3;
+        f[4 * i + 1] = e1 + e2;
+        f[4 * i + 2] = e1 - e2;
+        f[4 * i + 3] = e0 - e3;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int g0 = f[j] + f[8 + j], g1 = f[j] - f[8 + j];
+        int g2 = (f[4 + j] >> 1) - f[12 + j], g3 = f[4 + j] + (f[12 + j] >> 1);
+        h[j] = g0 + g3;
+        h[4 + j] = g1 + g2;
+        h[8 + j] = g1 - g2;
+        h[12 + j] = g0 - g3;
+    }
+}
+
+/* clip_u8(x >> 6), written as clamp-then-shift.  The natural form makes this compiler select
+ * v_ashr_pk_u8_i32 (gfx950) for pairs of samples and then OR the next samples into bits 16..31 of its
+ * result as if they were zero; on the hardware they keep the old contents of the destination register,
+ * which is the first operand here -- wrong bytes whenever that sum is negative or >= 65536 (found by the
+ * QP 51 noise case of tests/test_gpu_parity.py: one block of one picture). */
+DEVFN int intra_px(int x) { return (x < 0 ? 0 : x > 16383 ? 16383 : x) >> 6; }
+
+/* ================================================================== k_intra_fwd
+ * Half-wave per macroblock (lane roles as mb_code: 0..15 luma block, 16..19 Cb, 20..23 Cr). */
+__global__ __launch_bounds__(256) void k_intra_fwd(venc_geom g, venc_bufs B, venc_step S) {
+    const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
+    const int mb = S.mb0 + blockIdx.x * 8 + (tid >> 5);
+    if (mb >= S.mb1) return;
+    const int my = mb / g.mbw, mx = mb - my * g.mbw;
+    const bool act = l32 < 24, luma = l32 < 16;
+    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
+    const int k = l32 & 3;
+    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
+    int cstride, pw, ph;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
+    const bool cur_al = luma ? ((g.w & 3) == 0) : ((g.w & 7) == 0);
+    uint32_t cq[4] = {0, 0, 0, 0};
+    if (act) load_cur_rows(cur, cstride, pw, ph, (luma ? mx * 16 : mx * 8) + bx, (luma ? my * 16 : my * 8) + by, cur_al, cq);
+    int c[16], w[16];
+#pragma unroll
+    for (int y = 0; y < 4; y++)
+#pragma unroll
+        for (int x = 0; x < 4; x++) c[4 * y + x] = (int)((cq[y] >> (8 * x)) & 255u);
+    venc_fdct4(c, w);
+
+    const int qmf0 = luma ? g.ql.mf[0] : g.qc.mf[0], qmf1 = luma ? g.ql.mf[1] : g.qc.mf[1], qmf2 = luma ? g.ql.mf[2] : g.qc.mf[2];
+    const int qv0 = luma ? g.ql.v[0] : g.qc.v[0], qv1 = luma ? g.ql.v[1] : g.qc.v[1], qv2 = luma ? g.ql.v[2] : g.qc.v[2];
+    const int qbits = luma ? g.ql.qbits : g.qc.qbits, per = luma ? g.ql.per : g.qc.per;
+    const int f = luma ? g.ql.f_intra : g.qc.f_intra;
+    int lv[16], d[16], nnz = 0;
+    lv[0] = 0;
+    d[0] = 0;
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        const int r = venc_zigzag_ct(i);
+        const int cls = venc_pos_class(r);
+        const int mf = cls == 0 ? qmf0 : cls == 1 ? qmf1 : qmf2;
+        const int vv = cls == 0 ? qv0 : cls == 1 ? qv1 : qv2;
+        const int l = venc_quant_mag(w[r], mf, f, qbits);
+        lv[i] = l;
+        nnz += (l != 0);
+        d[r] = VENC_MUL24(l, vv) << per;
+    }
+    int h[16];
+    intra_idct4_raw(d, h);
+
+    const size_t gmb = (size_t)item * g.nmb + mb;
+    venc_mbinfo *info = B.mbinfo + gmb;
+    if (act) {
+        if (nnz) {
+            uint32_t p[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) p[i] = ((uint32_t)lv[2 * i] & 0xffffu) | ((uint32_t)lv[2 * i + 1] << 16);
+            uint4 *dst = (uint4 *)(B.levels + gmb * VENC_MB_COEFS + (luma ? l32 : 19 + (l32 - 16)) * 16);
+            dst[0] = make_uint4(p[0], p[1], p[2], p[3]);
+            dst[1] = make_uint4(p[4], p[5], p[6], p[7]);
+        }
+        info->nnz[luma ? blk_y(l32) * 4 + blk_x(l32) : l32] = (uint8_t)nnz;
+        int *rec = B.intra_rec + gmb * INTRA_REC_DWORDS;
+        rec[l32] = w[0];
+        const int es = intra_edge_slot(l32);
+        if (es >= 0) {
+            int4 *e = (int4 *)(rec + 24 + 8 * es);
+            e[0] = make_int4(h[3], h[7], h[11], h[15]);   /* right column */
+            e[1] = make_int4(h[12], h[13], h[14], h[15]); /* bottom row */
+        }
+    }
+    const uint32_t hnz = (uint32_t)(__ballot(act && nnz > 0) >> hbase);
+    if (l32 == 0) {
+        info->cbp = (uint8_t)((hnz & 0xffffu) ? 15 : 0);
+        info->cbpc = (uint8_t)(((hnz >> 16) & 0xffu) ? 2 : 0); /* 1 (DC only) is decided by k_intra_dc / k_intra_rec */
+        info->flags = 1;
+        B.mvsad[gmb] = 0;
+    }
+}
+
+/* ================================================================== k_intra_dc */
+DEVFN void lds_barrier() {
+    /* __syncthreads() would also wait for the global stores of the step (s_waitcnt vmcnt(0)) */
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#define DPP_QUAD_XOR1 0xB1 /* quad_perm [1,0,3,2] */
+#define DPP_QUAD_XOR2 0x4E /* quad_perm [2,3,0,1] */
+#define DPP_ROW_ROR(n) (0x120 + (n))
+/* natural-order Walsh-Hadamard butterflies over lane bits 0,1 (all lanes) and 2,3 (luma lanes):
+ * returns the 2-bit result in v2 and the 4-bit result in v4.  With luma lane = luma4x4BlkIdx the
+ * lane (x, y) ends up holding the coefficient (sig(x), sig(y)) of the standard's sequency-ordered
+ * 4x4 Hadamard, sig = 0,3,1,2; applying the same butterflies to the levels brings block (x, y)
+ * back to lane (x, y) because the matrix is symmetric. */
+DEVFN void intra_wht(int v, int l32, int &v2, int &v4) {
+    int o = (int)dpp_fetch<DPP_QUAD_XOR1, 0xf>((uint32_t)v, 0u);
+    v = o + ((l32 & 1) ? -v : v);
+    o = (int)dpp_fetch<DPP_QUAD_XOR2, 0xf>((uint32_t)v, 0u);
+    v = o + ((l32 & 2) ? -v : v);
+    v2 = v;
+    const int oa = (int)dpp_fetch<DPP_ROW_ROR(4), 0xf>((uint32_t)v, 0u), ob = (int)dpp_fetch<DPP_ROW_ROR(12), 0xf>((uint32_t)v, 0u);
+    v = (l32 & 4) ? oa - v : ob + v;
+    o = (int)dpp_fetch<DPP_ROW_ROR(8), 0xf>((uint32_t)v, 0u);
+    v = o + ((l32 & 8) ? -v : v);
+    v4 = v;
+}
+
+__global__ __launch_bounds__(1024) void k_intra_dc(venc_geom g, venc_bufs B, venc_step S, int cw) {
+    __shared__ int s_bot[2 * INTRA_CW_MAX][4][5];
+    __shared__ int s_last[INTRA_MAX_MBW][5]; /* bottom sums of the last row of the previous pass */
+    __shared__ uint4 s_ring[2][2 * INTRA_CW_MAX][INTRA_REC_DWORDS / 4];
+    const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
+    const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
+    const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
+    const int *recs = B.intra_rec + (size_t)item * g.nmb * INTRA_REC_DWORDS;
+
+    if (wv >= cw) {
+        /* ---- loader waves: records of step t go to ring stage t & 1 during step t - 1, fetched during step t - 2 */
+        const int nload = (int)blockDim.x - 64 * cw, lt = tid - 64 * cw;
+        for (int cb = r0; cb < r1; cb += 2 * cw) {
+            const int nr = min(2 * cw, r1 - cb), steps = g.mbw + nr - 1;
+            uint4 ld[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+#define INTRA_FETCH(t)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                \
+        const int u = lt + j * nload, row = u >> 5, mxx = (t) - row;                                               \
+        if (row < nr && mxx >= 0 && mxx < g.mbw)                                                                   \
+            ld[j] = ((const uint4 *)(recs + ((size_t)(cb + row) * g.mbw + mxx) * INTRA_REC_DWORDS))[u & 31];       \
+    }
+#define INTRA_PUT(t)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                \
+        const int u = lt + j * nload, row = u >> 5, mxx = (t) - row;                                               \
+        if (row < nr && mxx >= 0 && mxx < g.mbw) s_ring[(t) & 1][row][u & 31] = ld[j];                             \
+    }
+            INTRA_FETCH(0)
+            INTRA_PUT(0)
+            INTRA_FETCH(1)
+            lds_barrier();
+            for (int step = 0; step < steps; step++) {
+                INTRA_PUT(step + 1)
+                INTRA_FETCH(step + 2)
+                lds_barrier();
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    /* ---- compute waves: each half owns a macroblock row of the pass */
+    const int rw = wv + cw * (lane >> 5);
+    const bool act = l32 < 24, luma = l32 < 16;
+    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
+    const int k = l32 & 3;
+    const int es = intra_edge_slot(l32);
+    const bool e_right = luma ? blk_x(l32) == 3 : (k & 1) != 0, e_bot = luma ? blk_y(l32) == 3 : (k >> 1) != 0;
+    /* where this lane's luma DC level goes in the macroblock's DC record (zig-zag index of (sig(y), sig(x))) */
+    int zi = 0;
+    {
+        const int sy = (0x9C >> (2 * blk_y(l32 & 15))) & 3, sx = (0x9C >> (2 * blk_x(l32 & 15))) & 3; /* sig = 0,3,1,2 */
+        const int rp = sy * 4 + sx;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (venc_zigzag_ct(i) == rp) zi = i;
+    }
+    for (int cb = r0; cb < r1; cb += 2 * cw) {
+        const int nr = min(2 * cw, r1 - cb), steps = g.mbw + nr - 1;
+        const int my = cb + rw;
+        int leftY = 0, leftC0 = 0, leftC1 = 0;
+        lds_barrier();
+        for (int step = 0; step < steps; step++) {
+            const int mx = step - rw;
+            if (rw < nr && mx >= 0 && mx < g.mbw) {
+                const int *rg = (const int *)s_ring[step & 1][rw];
+                const int wdc = rg[l32];
+                int4 er = make_int4(0, 0, 0, 0), eb = make_int4(0, 0, 0, 0);
+                if (es >= 0) {
+                    er = *(const int4 *)(rg + 24 + 8 * es);
+                    eb = *(const int4 *)(rg + 28 + 8 * es);
+                }
+                const int mb = my * g.mbw + mx;
+                const bool aL = mx > 0, aT = my > r0;
+                int t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+                if (aT) {
+                    const int *sb = rw > 0 ? s_bot[rw - 1][mx & 3] : s_last[mx];
+                    t0 = sb[0], t1 = sb[1], t2 = sb[2], t3 = sb[3], t4 = sb[4];
+                }
+                int pred;
+                if (luma) {
+                    pred = (aL && aT) ? (leftY + t0 + 16) >> 5 : aL ? (leftY + 8) >> 4 : aT ? (t0 + 8) >> 4 : 128;
+                } else {
+                    const int sT = plane == 1 ? ((k & 1) ? t2 : t1) : ((k & 1) ? t4 : t3);
+                    const int sL = (k >> 1) ? leftC1 : leftC0;
+                    bool useT = aT, useL = aL;
+                    if (k == 1 && aT) useL = false;
+                    if (k == 2 && aL) useT = false;
+                    pred = (useT && useL) ? (sT + sL + 4) >> 3 : useT ? (sT + 2) >> 2 : useL ? (sL + 2) >> 2 : 128;
+                }
+                /* DC of the residual, Hadamard, quantisation, and back */
+                int y2, y4;
+                intra_wht(act ? wdc - 16 * pred : 0, l32, y2, y4);
+                const int dclv = luma ? venc_quant_luma_dc(y4, &g.ql) : venc_quant_chroma_dc(y2, &g.qc, 1);
+                int f2, f4;
+                intra_wht(dclv, l32, f2, f4);
+                const int d0 = luma ? venc_dequant_luma_dc(f4, &g.ql) : venc_dequant_chroma_dc(f2, &g.qc);
+                const int d0p = d0 + 64 * pred + 32;
+                /* edge samples of the reconstruction -> sums for the right and lower neighbours */
+                int pr = 0, pb = 0;
+                if (e_right)
+                    pr = intra_px(er.x + d0p) + intra_px(er.y + d0p) + intra_px(er.z + d0p) + intra_px(er.w + d0p);
+                if (e_bot)
+                    pb = intra_px(eb.x + d0p) + intra_px(eb.y + d0p) + intra_px(eb.z + d0p) + intra_px(eb.w + d0p);
+                /* luma: both sums to every luma lane (rotations inside the row of 16 lanes); sums <= 4080 */
+                uint32_t pk = luma ? ((uint32_t)pr << 16) | (uint32_t)pb : 0u;
+                pk += dpp_fetch<DPP_ROW_ROR(8), 0xf>(pk, 0u);
+                pk += dpp_fetch<DPP_ROW_ROR(4), 0xf>(pk, 0u);
+                pk += dpp_fetch<DPP_ROW_ROR(2), 0xf>(pk, 0u);
+                pk += dpp_fetch<DPP_ROW_ROR(1), 0xf>(pk, 0u);
+                leftY = (int)(pk >> 16);
+                /* chroma: the right-column sums of blocks 1 and 3 to the four lanes of the plane */
+                leftC0 = (int)dpp_fetch<0x55, 0xf>((uint32_t)pr, 0u); /* quad_perm [1,1,1,1] */
+                leftC1 = (int)dpp_fetch<0xFF, 0xf>((uint32_t)pr, 0u); /* quad_perm [3,3,3,3] */
+                int *sb = s_bot[rw][mx & 3];
+                if (l32 == 0) sb[0] = (int)(pk & 0xffffu);
+                if (!luma && act && (k >> 1)) sb[1 + 2 * (plane - 1) + (k & 1)] = pb;
+                if (rw == nr - 1 && cb + nr < r1) { /* a further pass follows: keep this row's bottom sums */
+                    if (l32 == 0) s_last[mx][0] = (int)(pk & 0xffffu);
+                    if (!luma && act && (k >> 1)) s_last[mx][1 + 2 * (plane - 1) + (k & 1)] = pb;
+                }
+                /* results (nobody in this kernel reads them back) */
+                const size_t gmb = (size_t)item * g.nmb + mb;
+                int16_t *lv_mb = B.levels + gmb * VENC_MB_COEFS;
+                if (act) B.intra_d0[gmb * 32 + l32] = d0p;
+                if (luma)
+                    lv_mb[16 * 16 + zi] = (int16_t)dclv;
+                else if (act) {
+                    lv_mb[(plane == 1 ? 17 : 18) * 16 + k] = (int16_t)dclv;
+                    if (k == 0) *(uint2 *)(lv_mb + (plane == 1 ? 17 : 18) * 16 + 4) = make_uint2(0u, 0u);
+                }
+                const uint32_t hdc = (uint32_t)(__ballot(act && !luma && dclv != 0) >> hbase);
+                if (l32 == 0) B.mbinfo[gmb].pad[0] = hdc ? 1 : 0;
+            }
+            lds_barrier();
+        }
+        __syncthreads();
+    }
+}
+
+/* ================================================================== k_intra_rec
+ * Half-wave per macroblock: inverse transform of the AC levels with d0 + 64 p (+ 32, already
+ * added) in position 0, reconstruction, and the final chroma coded_block_pattern. */
+__global__ __launch_bounds__(256) void k_intra_rec(venc_geom g, venc_bufs B, venc_step S) {
+    const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63, l32 = lane & 31;
+    const int mb = S.mb0 + blockIdx.x * 8 + (tid >> 5);
+    if (mb >= S.mb1) return;
+    const int my = mb / g.mbw, mx = mb - my * g.mbw;
+    const size_t gmb = (size_t)item * g.nmb + mb;
+    venc_mbinfo *info = B.mbinfo + gmb;
+    if (l32 == 0 && info->cbpc == 0 && info->pad[0]) info->cbpc = 1;
+    if (l32 >= 24) return;
+    const bool luma = l32 < 16;
+    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
+    const int k = l32 & 3;
+    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
+    const int qv0 = luma ? g.ql.v[0] : g.qc.v[0], qv1 = luma ? g.ql.v[1] : g.qc.v[1], qv2 = luma ? g.ql.v[2] : g.qc.v[2];
+    const int per = luma ? g.ql.per : g.qc.per;
+    const int nnz = info->nnz[luma ? blk_y(l32) * 4 + blk_x(l32) : l32];
+    const int d0p = B.intra_d0[gmb * 32 + l32];
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = 0;
+    if (nnz) {
+        const uint4 *src = (const uint4 *)(B.levels + gmb * VENC_MB_COEFS + (luma ? l32 : 19 + (l32 - 16)) * 16);
+        const uint4 a = src[0], b = src[1];
+        const uint32_t p[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 1; i < 16; i++) {
+            const int r = venc_zigzag_ct(i);
+            const int cls = venc_pos_class(r);
+            const int vv = cls == 0 ? qv0 : cls == 1 ? qv1 : qv2;
+            const int l = (int)(int16_t)((i & 1) ? p[i >> 1] >> 16 : p[i >> 1] & 0xffffu);
+            d[r] = VENC_MUL24(l, vv) << per;
+        }
+    }
+    int h[16];
+    intra_idct4_raw(d, h);
+    int wstride;
+    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
+    const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) v |= (uint32_t)intra_px(h[4 * y + x] + d0p) << (8 * x);
+        *(uint32_t *)(rec + (size_t)(py + y) * wstride + px) = v;
+    }
+}

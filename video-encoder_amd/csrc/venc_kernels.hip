@@ -636,8 +636,13 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                     sb[0] = botY, sb[1] = bcb0, sb[2] = bcb1, sb[3] = bcr0, sb[4] = bcr1;
                 }
             }
-            __syncthreads();
+            /* LDS-only barrier: __syncthreads() also waits for every global store and for the prefetch
+             * (s_waitcnt vmcnt(0)), which put a memory round trip on each step of the dependency chain */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         }
+        __syncthreads(); /* the next pass re-reads this pass's last reconstructed row from memory */
     }
 }
 
