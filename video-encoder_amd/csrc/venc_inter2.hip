@@ -213,7 +213,10 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
  * Tried and dropped: a third kind of block in this launch that searched the flagged macroblocks
  * exhaustively and transformed them, to hide k_me_fix's serial 13 us.  The search's registers
  * (or, capped, its spills in the shared prologue) cost the transform blocks more occupancy than
- * the hidden kernel was worth (74 us against 13 + 44 us). */
+ * the hidden kernel was worth (74 us against 13 + 44 us).
+ * Also tried: k_me_fix and a list-driven copy of this kernel on a third stream beside this launch
+ * (which then skipped the flagged macroblocks).  Bit-exact, but the two cross-stream event hand-offs
+ * per step cost more than the hidden 15 us: 1080p 5.63 -> 6.32 ms per clip, 2160p 17.6 -> 18.4 ms. */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_inter_fused(venc_geom g, venc_bufs B, venc_step S, int n_luma) {
     const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int bx = blockIdx.x;
