@@ -7,11 +7,15 @@
  *   unit 0  slice header (first macroblock of a slice), mb_skip_run .. mb_qp_delta, luma 8x8 block 0
  *   unit 1-3  luma 8x8 blocks 1-3 (four 4x4 blocks each)        unit 4  Cb and Cr DC
  *   unit 5  Cb AC (four blocks)                                 unit 6  Cr AC
- * Eight lanes per macroblock (the eighth idles), each unit appends to its own 64-word bit string in the
- * macroblock's region of mbbits; k_scan turns the seven lengths into offsets and k_pack gathers the strings.
+ * Each unit appends to its own 64-word bit string in the macroblock's region of mbbits; k_scan turns the seven
+ * lengths into offsets and k_pack gathers the strings.
  * The first version gave a whole macroblock to one lane: a wave then took as long as the heaviest of its 64
  * macroblocks -- up to 26 block codings, each behind a dependent load of its levels, ~100 us -- and the entropy
  * chain became the longer of the two chains of a step.  A unit is at most four blocks.
+ * The second gave every macroblock eight lanes: 45 us, but seven of eight lanes had nothing to code (a P macroblock
+ * of the 1080p clip averages 17-40 bits), and those 10 000 mostly idle waves held 80 % of the chip's wave slots
+ * beside the motion search of the next step.  Now k_skip lists the units that exist (header units of coded
+ * macroblocks, residual units with a coded_block_pattern bit) and k_cavlc_p gives one lane to each list entry.
  * I pictures (26 dense blocks in every macroblock) stay on k_cavlc (one lane per block, LDS concatenation).
  */
 
@@ -20,7 +24,10 @@
  * P_Skip decisions of a P picture (7.3.4), one lane per macroblock: no residual and the vector a decoder infers
  * (mb_is_p_skip).  The result is a bit mask of CODED macroblocks, one 64-bit word per 64 macroblocks of the picture
  * (wave ballot); k_cavlc_p derives mb_skip_run from it by looking backwards for the previous coded macroblock of the
- * slice -- a count-leading-zeros per word, and whole rows of skipped macroblocks are a handful of words. */
+ * slice -- a count-leading-zeros per word, and whole rows of skipped macroblocks are a handful of words.
+ * The same lane lists the macroblock's non-empty syntax units (mb << 3 | unit) for k_cavlc_p -- a wave scan and one
+ * atomic per wave; the order of the list is irrelevant, every unit writes to its own place -- and zeroes the
+ * macroblock's eight unit lengths, which the coded units then overwrite. */
 __global__ __launch_bounds__(256) void k_skip(venc_geom g, venc_bufs B, venc_step S) {
     const int item = blockIdx.z, tid = threadIdx.x;
     const int base = (S.mb0 & ~63) + blockIdx.x * 256; /* words are aligned to multiples of 64 macroblocks of the picture */
@@ -35,6 +42,35 @@ __global__ __launch_bounds__(256) void k_skip(venc_geom g, venc_bufs B, venc_ste
     const bool skip = in && mb_is_p_skip(g, B.mvsad + (size_t)item * g.nmb, mbc, mx, mx > 0, my > srow, cbp);
     const unsigned long long coded = __ballot(in && !skip);
     if ((tid & 63) == 0 && (mb >> 6) < (g.nmb + 63) / 64) B.codedmask[(size_t)item * ((g.nmb + 63) / 64) + (mb >> 6)] = coded;
+    /* units: 0 header (+ luma 8x8 block 0), 1-3 luma 8x8 blocks, 4 chroma DC, 5/6 Cb/Cr AC; a slice that ends in
+     * skipped macroblocks codes their count in unit 0 of its last macroblock */
+    uint32_t um = 0;
+    if (in) {
+        const int cbpl = cbp & 15, cbpc = cbp >> 4;
+        const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
+        /* unit 0 of a skipped macroblock still exists when it carries the slice header or the slice's last mb_skip_run */
+        um = skip ? ((mb == slice_last || (mx == 0 && my == srow)) ? 1u : 0u) : 1u | (uint32_t)(cbpl & 14) | (cbpc > 0 ? 16u : 0u) | (cbpc == 2 ? 96u : 0u);
+        *(uint4 *)(B.ubits + ((size_t)item * g.nmb + mb) * 8) = make_uint4(0u, 0u, 0u, 0u);
+    }
+    /* one atomic per block (the items' counters sit 128 bytes apart: atomics on one cache line serialise at ~11 ns each,
+     * which made this kernel 58 us at 2160p when every wave pulled and the ten counters shared a line) */
+    __shared__ uint32_t s_wtot[4], s_base;
+    const uint32_t n = (uint32_t)__popc(um), incl = wave_scan_incl(n);
+    if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+        s_base = total ? atomicAdd(&B.unit_count[item * VENC_COUNTER_STRIDE], total) : 0u;
+    }
+    __syncthreads();
+    uint32_t at = s_base + incl - n;
+    for (int k = 0; k < (tid >> 6); k++) at += s_wtot[k];
+    uint32_t *list = B.unit_list + (size_t)item * g.nmb * 7;
+    while (um) {
+        const int u = __builtin_ctz(um);
+        um &= um - 1u;
+        list[at++] = ((uint32_t)mb << 3) | (uint32_t)u;
+    }
 }
 
 /* P_Skip macroblocks directly before macroblock mb in its slice (first macroblock: `first`), from the coded-macroblock mask */
@@ -50,6 +86,7 @@ DEVFN uint32_t skip_run_before(const unsigned long long *mask, int mb, int first
     }
 }
 
+#define CAVLC_P_BLOCKS 160
 __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ uint32_t s_lv[256 * 9]; /* per lane: the 16 levels of the block being coded (+1 dword against bank conflicts) */
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
@@ -65,10 +102,16 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
               : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                         : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
-    const int unit = tid & 7;
-    const int mb_raw = S.mb0 + blockIdx.x * 32 + (tid >> 3);
-    const bool valid = mb_raw < S.mb1;
-    const int mb = valid ? mb_raw : S.mb0;
+    /* the other unit counter: read last by the previous P step's k_cavlc_p, filled next by the next one's k_skip */
+    if (blockIdx.x == 0 && tid == 0) B.unit_count_next[item * VENC_COUNTER_STRIDE] = 0;
+    const uint32_t count = B.unit_count[item * VENC_COUNTER_STRIDE];
+    const uint32_t *list = B.unit_list + (size_t)item * g.nmb * 7;
+    if (blockIdx.x * 256u >= count) return; /* whole block: nothing listed for it (the usual case for most of the grid) */
+  for (uint32_t base_e = blockIdx.x * 256u; base_e < count; base_e += gridDim.x * 256u) {
+    const bool valid = base_e + tid < count;
+    const uint32_t entry = list[valid ? base_e + tid : base_e];
+    const int unit = (int)(entry & 7u);
+    const int mb = (int)(entry >> 3);
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int srow = slice_first_row_of(g, my);
     const bool aL = mx > 0, aT = my > srow;
@@ -77,11 +120,13 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
     const uint4 *lp = (const uint4 *)(infos + (aL ? mb - 1 : mb));
     const uint4 *tp = (const uint4 *)(infos + (aT ? mb - g.mbw : mb));
     const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
+    if (base_e == blockIdx.x * 256u) {
 #pragma unroll
-    for (int k = 0; k < 3; k++)
-        if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
-    __syncthreads();
-    if (!valid) return;
+        for (int k = 0; k < 3; k++)
+            if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
+        __syncthreads();
+    }
+    if (!valid) continue;
 
     const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
     uint32_t *strip = s_lv + tid * 9;
@@ -167,5 +212,6 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
         }
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, first, maxc, nC, s_tab);
     }
-    ubits[unit] = (uint16_t)venc_bs_flush(&bs); /* the idle eighth lane writes 0 */
+    ubits[unit] = (uint16_t)venc_bs_flush(&bs);
+  }
 }

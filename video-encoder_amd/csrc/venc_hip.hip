@@ -68,6 +68,7 @@ struct venc_ctx {
     uint8_t *d_row_slice;
     uint16_t *d_rank, *d_cand;
     int intra_waves;
+    int unit_phase;   /* which of the two unit counters the next P step fills */
     int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
     int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
     int max_slice_mbs;
@@ -155,6 +156,8 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.ubits);
     (void)hipFree(c->b.mboff);
     (void)hipFree(c->b.codedmask);
+    (void)hipFree(c->b.unit_list);
+    (void)hipFree(c->b.unit_count);
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
@@ -320,6 +323,9 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.ubits, G * nmb * 8 * 2));
     OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.codedmask, G * ((nmb + 63) / 64) * 8));
+    OPEN_OK(hipMalloc(&b.unit_list, G * nmb * 7 * 4));
+    OPEN_OK(hipMalloc(&b.unit_count, 2 * G * VENC_COUNTER_STRIDE * 4));
+    OPEN_OK(hipMemset(b.unit_count, 0, 2 * G * VENC_COUNTER_STRIDE * 4));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
     b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
     OPEN_OK(hipMalloc(&b.refsum, G * b.refsum_item * 4));
@@ -485,6 +491,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     b.mvsad_prev = c->b.mvsad + (size_t)rs_prev * GN;
     b.levels = c->b.levels + (size_t)rs * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
+    b.unit_count = c->b.unit_count + (size_t)c->unit_phase * c->b.max_items * VENC_COUNTER_STRIDE;
+    b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.max_items * VENC_COUNTER_STRIDE;
+    if (!is_idr) c->unit_phase ^= 1;
     hipStream_t s1 = c->stream, s2 = c->overlap ? c->stream2 : c->stream;
     if (c->overlap && c->step_no % VENC_RING_WAIT == 0) {
         /* the entropy chain of step_no + WAIT - 1 - RING has released every slot the next WAIT steps overwrite */
@@ -551,7 +560,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
     else {
         hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
-        hipLaunchKernelGGL(k_cavlc_p, dim3((band_mbs + 31) / 32, 1, n_items), dim3(256), 0, s2, g, b, S);
+        /* one lane per listed unit: at most 7 per macroblock, about 1.2 on ordinary content -- blocks loop over the list */
+        const int cav_blocks = (7 * band_mbs + 255) / 256 < CAVLC_P_BLOCKS ? (7 * band_mbs + 255) / 256 : CAVLC_P_BLOCKS;
+        hipLaunchKernelGGL(k_cavlc_p, dim3(cav_blocks, 1, n_items), dim3(256), 0, s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {

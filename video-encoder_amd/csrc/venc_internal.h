@@ -76,6 +76,8 @@ typedef struct {
     int idr_id[VENC_MAX_ITEMS];
 } venc_step;
 
+#define VENC_COUNTER_STRIDE 32 /* words between per-item atomic counters: one cache line each */
+
 typedef struct {
     const uint8_t *in_base;
     size_t in_frame_stride;
@@ -91,6 +93,9 @@ typedef struct {
     uint16_t *ubits;            /* [G][nmb][8] bits of the macroblock's syntax units (k_cavlc*), turned into running ends by k_scan */
     uint32_t *mboff;
     unsigned long long *codedmask; /* [G][(nmb + 63) / 64] P pictures: bit = macroblock is coded (not P_Skip), k_skip */
+    uint32_t *unit_list;        /* [G][nmb * 7] P pictures: non-empty syntax units, mb << 3 | unit (k_skip -> k_cavlc_p) */
+    uint32_t *unit_count;       /* [G][32] (one per 128-byte line) entries of unit_list; two counters alternate between P steps (the launcher sets both pointers) */
+    uint32_t *unit_count_next;
     const int *slice_first_row; /* n_slices + 1 */
     const uint8_t *row_slice;   /* mbh */
     const uint16_t *me_rank;    /* [33*33] candidate (dyi*33+dxi) -> rank */
