@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip); 300 = the whole clip, ~15 s on 16 cores")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--serial-steps", action="store_true", help="one engine call per step (no overlap between consecutive steps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
     ap.add_argument("--mode", default="streams", choices=("streams", "slices"),
                     help="streams: one clip per GPU, no collective (default); slices: one clip, slice bands across GPUs")
@@ -129,7 +130,7 @@ def main():
     enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
                            gop_batch=gop_batch, device=local_rank, **band_kw)
     if not args.no_profile:
-        enc.profile(True, capacity=8 * frames * max(1, args.steps))
+        enc.profile(True, capacity=8 * frames * max(2, args.steps, args.warmup))
         # timed region: HIP-event pairs around the dominant kernel only (each pair stalls the stream for a
         # few microseconds; pairs around all nine kernels of a step slowed the step by ~20 %).  The other
         # kernels are timed in the untimed passes below.
@@ -155,19 +156,38 @@ def main():
             stream_info["frames"] = whole
         return None
 
+    # K steps = K passes over the resident clip.  streams mode hands them to the engine as ONE stream of K x frames
+    # (x264_venc_encode_resident_loop): the GPU works on pass k + 1 while the host packages pass k and hands it to the
+    # sink, as a server encoding batch after batch does; --serial-steps makes K separate calls, each of which returns only
+    # after its last frame was delivered.  slices mode: separate calls (the exchange callback is per call).
+    pipelined = not slices_mode and not args.serial_steps and args.steps > 1
     tally = None
-    for _ in range(args.warmup):
-        tally = one_pass()
+    if pipelined and args.warmup > 0:
+        # the warm-up goes through the same call; at least two passes, so that both halves of the engine's
+        # double-buffered output ring (and their host payload buffers) have been touched before the clock starts
+        enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=max(args.warmup, 2))
+    else:
+        for _ in range(args.warmup):
+            tally = one_pass()
     if not args.no_profile:
         enc.profile_read()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tally = one_pass()
+    if pipelined:
+        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=args.steps)
+    else:
+        for _ in range(args.steps):
+            tally = one_pass()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    bytes_per_step = int(tally.bytes) // (args.steps if pipelined else 1) if tally else None
     prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
     barrier()
+    if pipelined:
+        tally = one_pass()  # untimed: the digest of ONE pass, comparable across runs whatever --steps was
+        if not args.no_profile:
+            enc.profile_read()
+        barrier()
     # Untimed extra pass with the two kernel chains serialised on one stream: per-kernel durations
     # without the concurrency that the timed region uses (a kernel sharing the chip with another
     # chain's kernels takes longer although it does the same work).
@@ -206,7 +226,8 @@ def main():
                        "parallelism": ("%d slice bands of one stream, %s exchange of reconstructed rows per picture (%s)" % (
                            world, "halo (%d luma rows per edge)" % args.halo if args.halo else "whole-band", args.backend))
                        if slices_mode else ("1 stream per GPU, no collective" if world > 1 else "single GPU"),
-                       "bytes_per_step": int(tally.bytes) if tally else None,
+                       "steps_pipelined": pipelined,
+                       "bytes_per_step": bytes_per_step,
                        "bitstream_fnv1a": "%016x" % tally.fnv1a if tally else None,
                        "cpu_oracle_note": "bit-exact vs this repo's CPU oracle (tests/); parity with libx264 unpinned"},
         }

@@ -144,6 +144,15 @@ typedef int (*x264_venc_sink)(void *user, const x264_nal_t *nals, int nal_count,
 int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_stride, int n_frames, int64_t first_pts,
                               x264_venc_sink sink, void *user);
 
+/* The same over `repeats` back-to-back passes of the resident clip, as ONE stream of clip_frames * repeats
+ * frames (stream frame f reads clip frame f % clip_frames): the steady state of a server that encodes batch
+ * after batch.  Consecutive scheduling units overlap -- the GPU works on unit k + 1 while the host packages
+ * unit k and hands it to the sink -- which separate calls cannot do (each returns only after its last frame
+ * has been delivered).  With clip_frames a multiple of the GOP length the bitstream equals that of `repeats`
+ * separate calls. */
+int x264_venc_encode_resident_loop(x264_t *h, const void *d_frames, uint64_t frame_stride, int clip_frames, int repeats,
+                                   int64_t first_pts, x264_venc_sink sink, void *user);
+
 /* ready-made sink: frame/byte counters + FNV-1a digest of every payload byte */
 typedef struct {
     uint64_t frames, bytes, keyframes, fnv1a;

@@ -171,6 +171,35 @@ def test_resident_full_size_roundtrip(venc, orc):
     assert hashes[0] == hashes[1]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("gop_batch", [3, 1])
+def test_resident_loop_equals_separate_calls(venc, gop_batch):
+    """x264_venc_encode_resident_loop (what bench.py times): K passes of the resident clip as one stream give the
+    frames of K separate calls, in order, although consecutive scheduling units overlap on the GPU."""
+    import torch
+    w, h, n, keyint, reps = 352, 288, 12, 4, 3
+    fb = w * h * 3 // 2
+    buf = torch.empty(n * fb, dtype=torch.uint8, device="cuda")
+    assert venc.hip_lib().venc_synth_device(buf.data_ptr(), fb, w, h, 0, n, 0x1234ABCD) == 0
+    a, b = [], []
+    e = venc.X264Encoder(w, h, qp=28, slices=4, keyint=keyint, gop_batch=gop_batch)
+    for _ in range(reps):
+        assert e.encode_resident(buf.data_ptr(), fb, n, lambda payload, nals, pts, key: a.append((payload, pts % n, key))) == n
+    e.close()
+    e = venc.X264Encoder(w, h, qp=28, slices=4, keyint=keyint, gop_batch=gop_batch)
+    assert e.encode_resident(buf.data_ptr(), fb, n, lambda payload, nals, pts, key: b.append((payload, pts % n, key)),
+                             repeats=reps) == n * reps
+    assert [p for _, p, _ in b] == [t % n for t in range(n * reps)]
+    e.close()
+    e = venc.X264Encoder(w, h, qp=28, slices=4, keyint=keyint, gop_batch=gop_batch)
+    tally = e.encode_resident_tally(buf.data_ptr(), fb, n, repeats=reps)
+    assert tally.frames == n * reps and tally.bytes == sum(len(f[0]) for f in a)
+    e.close()
+    assert len(a) == len(b) == n * reps
+    for t, (x, y) in enumerate(zip(a, b)):
+        assert x == y, "frame %d" % t
+
+
 def _me_run(venc, frames, w, h, mode):
     import os
     os.environ["VENC_ME"] = mode

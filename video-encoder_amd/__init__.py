@@ -186,6 +186,8 @@ def x264_lib():
         L.x264_encoder_close.argtypes = [C.c_void_p]
         L.x264_venc_encode_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int64, C.c_void_p,
                                                 C.c_void_p]
+        L.x264_venc_encode_resident_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int64,
+                                                     C.c_void_p, C.c_void_p]
         L.x264_venc_engine.restype = C.c_void_p
         L.x264_venc_engine.argtypes = [C.c_void_p]
         _x264 = L
@@ -534,8 +536,9 @@ class X264Encoder:
                 out.append(self._collect(size, nals, n.value))
         return out
 
-    def encode_resident(self, dev_ptr, frame_stride, n_frames, sink=None, first_pts=0):
-        """Encode frames already in HBM; sink(payload_bytes, nal_list, pts, keyframe) per frame, or count only."""
+    def encode_resident(self, dev_ptr, frame_stride, n_frames, sink=None, first_pts=0, repeats=1):
+        """Encode frames already in HBM; sink(payload_bytes, nal_list, pts, keyframe) per frame, or count only.
+        repeats > 1: that many passes of the clip as one stream (x264_venc_encode_resident_loop)."""
         def _cb(user, nals, n, size, pic):
             if sink is not None:
                 base = C.addressof(nals[0].p_payload.contents)
@@ -544,21 +547,22 @@ class X264Encoder:
                 sink(C.string_at(base, size), lst, pic.contents.i_pts, bool(pic.contents.b_keyframe))
             return 0
         cb = SINK_FN(_cb)
-        r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts,
-                                             C.cast(cb, C.c_void_p), None)
+        r = self.L.x264_venc_encode_resident_loop(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, repeats, first_pts,
+                                                  C.cast(cb, C.c_void_p), None)
         if r < 0:
-            raise self._error("x264_venc_encode_resident failed: %s" % hip_lib().venc_last_error().decode())
+            raise self._error("x264_venc_encode_resident_loop failed: %s" % hip_lib().venc_last_error().decode())
         return r
 
-    def encode_resident_tally(self, dev_ptr, frame_stride, n_frames, first_pts=0):
-        """Same, with the C tally sink (no Python in the loop): returns X264Tally."""
+    def encode_resident_tally(self, dev_ptr, frame_stride, n_frames, first_pts=0, repeats=1):
+        """Same, with the C tally sink (no Python in the loop): returns X264Tally.  repeats > 1: that many passes of
+        the resident clip as one stream (x264_venc_encode_resident_loop): consecutive passes overlap."""
         t = X264Tally()
         fn = C.cast(self.L.x264_venc_tally_sink, C.c_void_p)
-        r = self.L.x264_venc_encode_resident(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, first_pts, fn,
-                                             C.cast(C.pointer(t), C.c_void_p))
-        if r != n_frames:
-            raise self._error("x264_venc_encode_resident delivered %d of %d frames: %s" % (
-                r, n_frames, hip_lib().venc_last_error().decode()))
+        r = self.L.x264_venc_encode_resident_loop(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, repeats, first_pts, fn,
+                                                  C.cast(C.pointer(t), C.c_void_p))
+        if r != n_frames * repeats:
+            raise self._error("x264_venc_encode_resident_loop delivered %d of %d frames: %s" % (
+                r, n_frames * repeats, hip_lib().venc_last_error().decode()))
         return t
 
     # ---- per-kernel HIP-event timing of the engine behind this encoder

@@ -242,7 +242,21 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     } while (0)
 
     OPEN_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    OPEN_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {
+        /* VENC_ENTROPY_CUS=n: the entropy chain's stream may only use n of the chip's CUs (queue CU mask; the mask bits
+         * interleave the XCDs, so the first n bits are n/8 CUs of every XCD).  The chain is latency bound and its
+         * blocks otherwise land on every CU, where their LDS and registers cost the motion search its third block. */
+        const char *e = getenv("VENC_ENTROPY_CUS");
+        const int ncu = e ? atoi(e) : 0;
+        hipDeviceProp_t prop;
+        OPEN_OK(hipGetDeviceProperties(&prop, cfg->device));
+        if (ncu >= 8 && ncu < prop.multiProcessorCount) {
+            uint32_t mask[16] = {0};
+            for (int i = 0; i < ncu && i < 512; i++) mask[i >> 5] |= 1u << (i & 31);
+            OPEN_OK(hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)((prop.multiProcessorCount + 31) / 32), mask));
+        } else
+            OPEN_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    }
     for (int i = 0; i < VENC_EVENTS; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_main[i], hipEventDisableTiming));

@@ -307,29 +307,41 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
     const int item = blockIdx.z, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
+    if (blockIdx.x >= count) return;
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+    const int dy0 = wave * FIX_NDY;          /* first dy index of this wave */
+    const int dxi = lane < 33 ? lane : 32;   /* lanes 33..63 repeat column 32 and are ignored */
+    /* the ranks of this lane's candidates do not depend on the macroblock: fetched before anything else, used last */
+    uint32_t rk[FIX_NDY];
+#pragma unroll
+    for (int k = 0; k < FIX_NDY; k++) rk[k] = (dy0 + k <= 32 && lane < 33) ? (uint32_t)B.me_rank[(dy0 + k) * 33 + dxi] : 0x7ffu;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const int mb = (int)B.fix_list[(size_t)item * g.nmb + i];
         const int mx = mb % g.mbw, my = mb / g.mbw;
         const int x0 = mx * 16, y0 = my * 16;
         __syncthreads();
-        for (int k = tid; k < 52 * 12; k += 256) {
-            const int r = k / 12, d = k - r * 12;
-            const uint8_t *row = ref + (size_t)clampi(y0 - 16 + r, 0, g.ch - 1) * rstride;
-            const int xb = x0 - 16 + 4 * d;
-            s_win[r * FIX_WD + d] = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
-                                    ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) |
-                                    ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
-        }
-        if (tid < 52) s_win[tid * FIX_WD + 12] = 0;
-        if (tid < 64) {
-            const int r = tid >> 2, d = tid & 3;
+        if (tid < 52 * 3) { /* 52 rows x three 16-byte pieces; a piece is wholly inside or wholly outside the coded picture */
+            const int r = tid / 3, q = tid - r * 3;
+            const int x = x0 - 16 + 16 * q;
+            uint4 v = *(const uint4 *)(ref + (size_t)clampi(y0 - 16 + r, 0, g.ch - 1) * rstride + clampi(x, 0, g.cw - 16));
+            if (x < 0) {
+                const uint32_t e = (v.x & 255u) * 0x01010101u;
+                v = make_uint4(e, e, e, e);
+            } else if (x >= g.cw) {
+                const uint32_t e = (v.w >> 24) * 0x01010101u;
+                v = make_uint4(e, e, e, e);
+            }
+            uint32_t *d = s_win + r * FIX_WD + 4 * q; /* rows are 52 bytes apart: dword stores */
+            d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+            if (q == 0) s_win[r * FIX_WD + 12] = 0;
+        } else if (tid >= 192) {
+            const int t = tid - 192, r = t >> 2, d = t & 3;
             const uint8_t *row = cur + (size_t)min(y0 + r, g.h - 1) * cstride;
             const int xb = x0 + 4 * d;
-            s_cur[tid] = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
-                         ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
+            s_cur[t] = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
+                       ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
         }
         __syncthreads();
         uint32_t c[16][4];
@@ -340,8 +352,6 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
         uint32_t acc[FIX_NDY];
 #pragma unroll
         for (int k = 0; k < FIX_NDY; k++) acc[k] = 0;
-        const int dy0 = wave * FIX_NDY;          /* first dy index of this wave */
-        const int dxi = lane < 33 ? lane : 32;   /* lanes 33..63 repeat column 32 and are ignored */
         const int dw = dxi >> 2;
         const uint32_t sh = (uint32_t)(dxi & 3);
 #pragma unroll
@@ -363,20 +373,22 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
                 }
             }
         }
-        uint32_t best = 0xffffffffu;
+        /* key = SAD << 11 | rank is unique per candidate: the thread that holds the block's minimum knows its own
+         * displacement (no table lookup from the winning rank) */
+        uint32_t mine = 0xffffffffu;
+        int mine_k = 0;
 #pragma unroll
         for (int k = 0; k < FIX_NDY; k++) {
-            const int dyi = dy0 + k;
-            if (dyi <= 32 && lane < 33) best = min(best, (acc[k] << 11) | B.me_rank[dyi * 33 + dxi]);
+            const uint32_t key = rk[k] == 0x7ffu ? 0xffffffffu : (acc[k] << 11) | rk[k];
+            if (key < mine) mine = key, mine_k = k;
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
-        if (lane == 0) s_best[wave] = best;
+        const uint32_t hm = half_min32(mine, lane);
+        const uint32_t wm = min((uint32_t)__builtin_amdgcn_readlane((int)hm, 0), (uint32_t)__builtin_amdgcn_readlane((int)hm, 32));
+        if (lane == 0) s_best[wave] = wm;
         __syncthreads();
-        if (tid == 0) {
-            best = min(min(s_best[0], s_best[1]), min(s_best[2], s_best[3]));
-            const uint32_t cand = B.me_cand[best & 2047u];
-            const int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
+        const uint32_t best = min(min(s_best[0], s_best[1]), min(s_best[2], s_best[3]));
+        if (mine == best) {
+            const int dx = dxi - 16, dy = dy0 + mine_k - 16;
             B.mvsad[(size_t)item * g.nmb + mb] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
         }
     }

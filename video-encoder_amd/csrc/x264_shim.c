@@ -61,6 +61,8 @@ struct x264_t {
     h264_seq seq;
     int nal_cap;
     int external_input; /* venc_set_input is active (resident mode) */
+    double trace_t0;    /* VENC_TRACE: start of the resident call (0 = no trace) */
+    int64_t ext_clip;   /* resident mode: frames in the resident clip; stream frame f reads clip frame f % ext_clip */
     int band_first, band_count; /* slices coded by this encoder (slice-parallel mode), 0/0 = all */
 };
 
@@ -252,7 +254,7 @@ static int launch_pending(x264_t *h, int flush) {
         if (h->gop_batch == 1) {
             const int64_t f = h->n_launched;
             shim_frame *fr = &h->ring[f % h->pool];
-            int in_slot = h->external_input ? (int)f : (int)(f % h->pool), out_slot = (int)(f % h->pool);
+            int in_slot = h->external_input ? (int)(f % h->ext_clip) : (int)(f % h->pool), out_slot = (int)(f % h->pool);
             int idr_id = (int)(h->gop_counter & 1);
             if (venc_encode_step(h->ctx, 1, &in_slot, &out_slot, fr->is_idr, (int)(f % h->keyint) & 15, &idr_id) != 0) return -1;
             if (fr->is_idr) h->gop_counter++;
@@ -268,7 +270,7 @@ static int launch_pending(x264_t *h, int flush) {
                 for (int g = 0; g < gops; g++) {
                     if (g == gops - 1 && rem && t >= rem) break;
                     const int64_t f = h->n_launched + (int64_t)g * h->keyint + t;
-                    in_slots[items] = h->external_input ? (int)f : (int)(f % h->pool);
+                    in_slots[items] = h->external_input ? (int)(f % h->ext_clip) : (int)(f % h->pool);
                     out_slots[items] = (int)(f % h->pool);
                     idr_ids[items] = (int)((h->gop_counter + g) & 1);
                     items++;
@@ -343,11 +345,14 @@ static int assemble_next_unit(x264_t *h) {
         if (assemble_frame(h, base) != 0) return -1;
     } else {
         const int gops = (n + h->keyint - 1) / h->keyint;
-        for (int t = 0; t < h->keyint; t++)
+        for (int t = 0; t < h->keyint; t++) {
             for (int g = 0; g < gops; g++) {
                 const int64_t k = (int64_t)g * h->keyint + t;
                 if (k < n && assemble_frame(h, base + k) != 0) return -1;
             }
+            if (h->trace_t0 > 0 && (t % 5 == 0 || t == h->keyint - 1))
+                fprintf(stderr, "venc trace:     step %d of unit at frame %lld packaged at +%.3f ms\n", t, (long long)base, now_ms() - h->trace_t0);
+        }
     }
     h->n_asm += n;
     return 0;
@@ -401,9 +406,17 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
 
 int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_stride, int n_frames, int64_t first_pts,
                               x264_venc_sink sink, void *user) {
-    if (!h || !d_frames || n_frames < 1 || h->n_in != h->n_out) return -1;
-    if (venc_set_input(h->ctx, d_frames, (size_t)frame_stride, n_frames) != 0) return -1;
+    return x264_venc_encode_resident_loop(h, d_frames, frame_stride, n_frames, 1, first_pts, sink, user);
+}
+
+int x264_venc_encode_resident_loop(x264_t *h, const void *d_frames, uint64_t frame_stride, int clip_frames, int repeats,
+                                   int64_t first_pts, x264_venc_sink sink, void *user) {
+    if (!h || !d_frames || clip_frames < 1 || repeats < 1 || h->n_in != h->n_out) return -1;
+    if ((int64_t)clip_frames * repeats > 0x7fffffff) return -1;
+    if (venc_set_input(h->ctx, d_frames, (size_t)frame_stride, clip_frames) != 0) return -1;
+    const int n_frames = clip_frames * repeats;
     h->external_input = 1;
+    h->ext_clip = clip_frames;
     /* frame numbering restarts so that resident frame f is input slot f */
     h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
     int delivered = 0, f = 0;
@@ -412,6 +425,7 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
     x264_picture_t po;
     const int trace = getenv("VENC_TRACE") != NULL; /* host-side phase times to stderr */
     double t_launch = 0, t_asm = 0, t_sink = 0, t0 = now_ms(), ta;
+    h->trace_t0 = trace ? t0 : 0;
     while (f < n_frames || h->n_out < h->n_in) {
         ta = now_ms();
         /* keep the GPU queue full: register frames while output slots are free */
@@ -440,6 +454,8 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
             delivered++;
         }
         t_sink += now_ms() - ta;
+        if (trace)
+            fprintf(stderr, "venc trace:   +%.3f ms: %d frames delivered, %lld launched\n", now_ms() - t0, delivered, (long long)h->n_launched);
     }
     if (trace)
         fprintf(stderr, "venc trace: %d frames, total %.3f ms = launch %.3f + package(wait+escape) %.3f + sink %.3f\n", delivered,
