@@ -200,6 +200,52 @@ def test_resident_loop_equals_separate_calls(venc, gop_batch):
         assert x == y, "frame %d" % t
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,qp,slices", [(352, 288, 26, 4), (176, 144, 51, 2), (178, 146, 12, 3), (176, 464, 30, 1)])
+def test_intra_three_kernels_equal_the_wavefront_kernel(venc, w, h, qp, slices, monkeypatch):
+    """I pictures: transform / DC chain / reconstruction as three kernels (venc_intra2.hip) against the one-kernel
+    wavefront k_intra (VENC_INTRA=legacy, read when an engine is opened): same reconstruction, levels and macroblock
+    records.  QP 51 noise is the case that exposed the v_ashr_pk_u8_i32 selection."""
+    frames = noise_frames(w, h, 4, 0x1234ABCD)
+    monkeypatch.setenv("VENC_INTRA", "legacy")
+    ea = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2)
+    monkeypatch.delenv("VENC_INTRA")
+    eb = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2)
+    for t, (y, u, v) in enumerate(frames):
+        for e in (ea, eb):
+            e.upload(t % 2, y, u, v)
+            e.encode_step([t % 2], [t % 2], True, 0, [t & 1])
+            e.sync()
+        for p in range(3):
+            assert np.array_equal(ea.debug(4 + p), eb.debug(4 + p)), "plane %d frame %d" % (p, t)
+        assert np.array_equal(ea.debug(1), eb.debug(1)), "levels frame %d" % t
+        assert np.array_equal(ea.debug(2)[:, :27], eb.debug(2)[:, :27]), "macroblock records frame %d" % t
+        assert ea.get_slices(t % 2) == eb.get_slices(t % 2), "slices frame %d" % t
+    ea.close()
+    eb.close()
+
+
+@pytest.mark.gpu
+def test_cu_masked_entropy_stream_changes_nothing(venc, monkeypatch):
+    """VENC_ENTROPY_CUS (the entropy chain's stream confined to a subset of the CUs, an experiment kept behind an
+    environment variable) must not change the stream."""
+    import torch
+    w, h, n, keyint = 352, 288, 8, 4
+    fb = w * h * 3 // 2
+    buf = torch.empty(n * fb, dtype=torch.uint8, device="cuda")
+    assert venc.hip_lib().venc_synth_device(buf.data_ptr(), fb, w, h, 0, n, 0x1234ABCD) == 0
+    outs = []
+    for cus in (None, "64"):
+        if cus:
+            monkeypatch.setenv("VENC_ENTROPY_CUS", cus)
+        e = venc.X264Encoder(w, h, qp=28, slices=4, keyint=keyint, gop_batch=2)
+        got = []
+        assert e.encode_resident(buf.data_ptr(), fb, n, lambda payload, nals, pts, key: got.append(payload)) == n
+        e.close()
+        outs.append(got)
+    assert outs[0] == outs[1]
+
+
 def _me_run(venc, frames, w, h, mode):
     import os
     os.environ["VENC_ME"] = mode
