@@ -75,6 +75,7 @@ def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x
     (144, 32, 24, 2, 3, 4, "noise"),       # one tile row, second tile column partly outside
     (130, 258, 36, 5, 3, 4, "noise"),      # 9 x 17 macroblocks: ragged right and bottom tiles, uneven slices
     (176, 464, 28, 1, 2, 3, "noise"),      # 29 MB rows in one slice: two passes of the intra DC chain (24 + 5 rows)
+    (7680, 4320, 32, 8, 2, 2, "synth"),    # 8K: 480 x 270 macroblocks, 34-row slices (two passes of the intra DC chain), 60 tiles per row
 ])
 def test_stages_match_oracle(venc, orc, w, h, qp, slices, keyint, n, kind):
     _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind)
