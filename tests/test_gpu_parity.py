@@ -140,6 +140,17 @@ def test_gop_batched_equals_streaming(venc):
     assert [f.payload for f in a] == [f.payload for f in b]
 
 
+def test_sixty_four_items_in_lock_step(venc):
+    """The engine's maximum: 64 closed GOPs advanced per step (ragged last unit: 70 GOPs = 64 + 6), against one at a time."""
+    w, h, keyint, gops = 80, 48, 3, 70
+    frames = [venc.synth_frame(w, h, t, 5) for t in range(keyint * gops)]
+    a = _x264_stream(venc, frames, w, h, qp=30, slices=3, keyint=keyint, gop_batch=1)
+    b = _x264_stream(venc, frames, w, h, qp=30, slices=3, keyint=keyint, gop_batch=64)
+    assert len(a) == len(b) == keyint * gops
+    assert [f.payload for f in a] == [f.payload for f in b]
+    assert [f.pts for f in b] == list(range(keyint * gops))
+
+
 def test_resident_full_size_roundtrip(venc, orc):
     """BASELINE config 2 geometry at full size: size-independent properties --
     own decoder reproduces a decodable stream, GOP-batched == streaming hash,
