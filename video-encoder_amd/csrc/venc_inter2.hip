@@ -223,7 +223,12 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
  * the hidden kernel was worth (74 us against 13 + 44 us).
  * Also tried: k_me_fix and a list-driven copy of this kernel on a third stream beside this launch
  * (which then skipped the flagged macroblocks).  Bit-exact, but the two cross-stream event hand-offs
- * per step cost more than the hidden 15 us: 1080p 5.63 -> 6.32 ms per clip, 2160p 17.6 -> 18.4 ms. */
+ * per step cost more than the hidden 15 us: 1080p 5.63 -> 6.32 ms per clip, 2160p 17.6 -> 18.4 ms.
+ * And a second attempt at the third kind of block with a register-light search (a quarter-wave per candidate, 16
+ * candidates per round, ranks in LDS, 69 rounds; the fix blocks of all items first in dispatch order, one listed
+ * macroblock per block).  It fits the 80 VGPRs, but on a chip saturated with transform waves the search chain takes
+ * ~45 us (12 us as a kernel of its own on an empty chip), longer than the 37 us transform, and its prologue spills
+ * cost every block ~5 %: 1080p +1.7 %, 2160p -1.3 % -- noise.  Dropped. */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_inter_fused(venc_geom g, venc_bufs B, venc_step S, int n_luma) {
     const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int bx = blockIdx.x;
