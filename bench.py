@@ -51,7 +51,7 @@ WORKLOADS = {
     "cif": dict(w=352, h=288, frames=300, keyint=30, qp=26, slices=8, name="CIF smoke workload"),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
-ME_EVENT_STRIDE = 4             # timed region: HIP-event pairs around every 4th k_me launch (each pair stalls the stream ~8 us)
+ME_EVENT_STRIDE = 8             # timed region: HIP-event pairs around every 8th k_me launch (each pair stalls the stream ~8 us: 1 in 4 cost 3.6 % of a 1080p pass)
 ME_ALGO_BYTES_PER_PX = 2.0      # k_me reads cur Y (1.0) + ref Y (1.0) per P-frame pixel
 
 
@@ -265,7 +265,9 @@ def main():
                                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": me_n, "launches_sampled_one_in": ME_EVENT_STRIDE,
                                    "search_positions_per_s": round(1089.0 * 256.0 * px_per_launch / 256.0 / avg_s, 1),
                                    "timed_region_runs_two_kernel_chains_concurrently": True,
-                                   "events_dropped": dropped}
+                                   "events_dropped": dropped,
+                                   "note": "HBM is the bound this line is priced against; the kernel itself is VALU/LDS bound "
+                                           "(59 % of the VALU issue rate alone on the chip: profiles/r01_i_sq_counters_1080p_isolated.txt, DESIGN.md 4.1)"}
                 iso_ms, iso_n = prof_iso.get("k_me", (0.0, 0))
                 if iso_n:
                     iso_s = iso_ms / iso_n * 1e-3
