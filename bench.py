@@ -69,8 +69,9 @@ def cpu_baseline(wl, frames, threads):
     dt = time.perf_counter() - t0
     enc.close()
     return dict(value=round(frames * w * h / dt / 1e6, 3), unit="Mpixels/s", cores=threads, kind="port",
-                sample="first %d frames (1 I + %d P) of the same %dx%d clip, %d OpenMP threads, %.1f s" % (
-                    frames, frames - 1, w, h, threads, dt))
+                sample="first %d frames (%d I + %d P, closed GOPs of %d) of the same %dx%d clip, %d OpenMP threads, %.1f s" % (
+                    frames, (frames + wl["keyint"] - 1) // wl["keyint"], frames - (frames + wl["keyint"] - 1) // wl["keyint"],
+                    wl["keyint"], w, h, threads, dt))
 
 
 def main():
