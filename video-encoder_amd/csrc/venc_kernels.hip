@@ -2,12 +2,17 @@
  * venc_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the
  * per-macroblock encode loop.  No MFMA: nothing here is a dense contraction.
  *
- *   k_me     a4.1  exhaustive +-16 integer-pel 16x16 SAD search, LDS-staged window
- *   k_inter  a4.2/3/5  MC prediction, 4x4 core transform, quantisation, reconstruction (P)
- *   k_intra  a4.2/3/5  Intra16x16-DC wavefront per slice (I)
- *   k_cavlc  a4.4  zig-zag/run-level entropy coding, one lane per 4x4 block
- *   k_scan   a4.4  per-slice exclusive scan of macroblock bit lengths
- *   k_pack   a4.4  owner-gather bit packing straight into pinned host memory
+ * This file: the shared device helpers, the entropy chain's common kernels and the first-generation kernels that
+ * are kept as selectable variants and as on-GPU test oracles:
+ *   k_me_dense  a4.1  exhaustive +-16 integer-pel 16x16 SAD search, LDS-staged window (VENC_ME=dense)
+ *   k_inter     a4.2/3/5  MC prediction, 4x4 core transform, quantisation, reconstruction (P; VENC_INTER=legacy)
+ *   k_intra     a4.2/3/5  Intra16x16-DC wavefront per slice (I; VENC_INTRA=legacy)
+ *   k_cavlc     a4.4  zig-zag/run-level entropy coding of I pictures, one lane per 4x4 block
+ *   k_scan      a4.4  per-slice exclusive scan of the syntax units' bit lengths
+ *   k_pack      a4.4  owner-gather bit packing straight into pinned host memory
+ *   k_band_copy a4.5  slice-parallel mode: rows of a band <-> exchange chunk
+ * The shipped path's other kernels: venc_me3.hip (k_me_pool), venc_me2.hip (k_me_fix), venc_inter2.hip
+ * (k_inter_fused), venc_intra2.hip (k_intra_fwd / k_intra_dc / k_intra_rec), venc_cavlc_p.hip (k_skip, k_cavlc_p).
  *
  * Row references (a4.x) are SURVEY.md section 8a; the reference has no source
  * for any of these stages (they sit behind x264_encoder_encode(),
