@@ -86,28 +86,33 @@ DEVFN uint32_t skip_run_before(const unsigned long long *mask, int mb, int first
     }
 }
 
-#define CAVLC_P_BLOCKS 160
-__global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ uint32_t s_lv[256 * 9]; /* per lane: the 16 levels of the block being coded (+1 dword against bank conflicts) */
+/* Blocks of 1024 lanes (pictures up to ~2.5K x 10 items; 512 beyond, where the listed units need the whole chip
+ * anyway): the listed units of a picture then occupy a hundred CUs instead of landing, a few waves each, on all
+ * 256 -- any resident block of this kernel (62 VGPRs, LDS) costs the motion search of the next step, which runs
+ * beside it, its third block on that CU.  1080p: k_me_pool beside the entropy chain 87 -> 78 us with 1024 lanes per
+ * block, 85 us with 512; 2160p: no difference for the search, but 1024-lane blocks wait for CUs with room for their
+ * 38 KB (k_cavlc_p 107 -> 245 us beside the search).  The per-lane strips are dynamic LDS: 36 bytes per lane. */
+#define CAVLC_P_MAX_THREADS 1024
+#define CAVLC_P_BLOCK_LANES (40 * 1024) /* lanes per item: blocks loop over longer lists */
+__global__ __launch_bounds__(CAVLC_P_MAX_THREADS) void k_cavlc_p(venc_geom g, venc_bufs B, venc_step S) {
+    extern __shared__ uint32_t s_lv[]; /* per lane: the 16 levels of the block being coded (+1 dword against bank conflicts) */
+    const uint32_t nthreads = blockDim.x;
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
     const int item = blockIdx.z, tid = threadIdx.x;
-    uint16_t tv[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int i = tid + 256 * k;
-        tv[k] = i >= VENC_TAB_SIZE      ? (uint16_t)0
-              : i < VENC_TAB_TOKEN_CDC  ? venc_vlc_coeff_token[i]
-              : i < VENC_TAB_TZ         ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
-              : i < VENC_TAB_TZ_CDC     ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
-              : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
-                                        : venc_vlc_run_before[i - VENC_TAB_RUN];
-    }
     /* the other unit counter: read last by the previous P step's k_cavlc_p, filled next by the next one's k_skip */
     if (blockIdx.x == 0 && tid == 0) B.unit_count_next[item * VENC_COUNTER_STRIDE] = 0;
     const uint32_t count = B.unit_count[item * VENC_COUNTER_STRIDE];
     const uint32_t *list = B.unit_list + (size_t)item * g.nmb * 7;
-    if (blockIdx.x * 256u >= count) return; /* whole block: nothing listed for it (the usual case for most of the grid) */
-  for (uint32_t base_e = blockIdx.x * 256u; base_e < count; base_e += gridDim.x * 256u) {
+    if (blockIdx.x * nthreads >= count) return; /* whole block: nothing listed for it */
+    for (int i = tid; i < VENC_TAB_SIZE; i += (int)nthreads) {
+        s_tab[i] = i < VENC_TAB_TOKEN_CDC  ? venc_vlc_coeff_token[i]
+                 : i < VENC_TAB_TZ         ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
+                 : i < VENC_TAB_TZ_CDC     ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
+                 : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
+                                           : venc_vlc_run_before[i - VENC_TAB_RUN];
+    }
+    __syncthreads();
+  for (uint32_t base_e = blockIdx.x * nthreads; base_e < count; base_e += gridDim.x * nthreads) {
     const bool valid = base_e + tid < count;
     const uint32_t entry = list[valid ? base_e + tid : base_e];
     const int unit = (int)(entry & 7u);
@@ -120,12 +125,6 @@ __global__ __launch_bounds__(256) void k_cavlc_p(venc_geom g, venc_bufs B, venc_
     const uint4 *lp = (const uint4 *)(infos + (aL ? mb - 1 : mb));
     const uint4 *tp = (const uint4 *)(infos + (aT ? mb - g.mbw : mb));
     const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
-    if (base_e == blockIdx.x * 256u) {
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
-        __syncthreads();
-    }
     if (!valid) continue;
 
     const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);

@@ -575,8 +575,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     else {
         hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
         /* one lane per listed unit: at most 7 per macroblock, about 1.2 on ordinary content -- blocks loop over the list */
-        const int cav_blocks = (7 * band_mbs + 255) / 256 < CAVLC_P_BLOCKS ? (7 * band_mbs + 255) / 256 : CAVLC_P_BLOCKS;
-        hipLaunchKernelGGL(k_cavlc_p, dim3(cav_blocks, 1, n_items), dim3(256), 0, s2, g, b, S);
+        const int cav_threads = (long long)band_mbs * n_items <= 131072 ? CAVLC_P_MAX_THREADS : 512;
+        const int cav_need = (7 * band_mbs + cav_threads - 1) / cav_threads;
+        const int cav_blocks = cav_need < CAVLC_P_BLOCK_LANES / cav_threads ? cav_need : CAVLC_P_BLOCK_LANES / cav_threads;
+        hipLaunchKernelGGL(k_cavlc_p, dim3(cav_blocks, 1, n_items), dim3(cav_threads), (size_t)cav_threads * 36, s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {
