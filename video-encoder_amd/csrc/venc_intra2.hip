@@ -179,41 +179,66 @@ DEVFN void intra_wht(int v, int l32, int &v2, int &v4) {
     v4 = v;
 }
 
+/* Loader wave of k_intra_dc: the records of step t travel from memory straight into ring stage t & 3
+ * (global_load_lds_dwordx4: no registers in between), issued three steps ahead.  A wave fetches NJ runs of 64 units
+ * (16 bytes each) per step -- NJ is fixed per wave and pass, so "the records of step s + 1 have landed" is
+ * s_waitcnt vmcnt(2 NJ): the fetches of steps s + 2 and s + 3 stay in flight.  Lanes without a record (rows beyond
+ * the pass, macroblocks beyond the row) read a dummy address; their ring slots are never read.  The first version
+ * fetched one step ahead into registers and waited with vmcnt(0): a step of the chain then took as long as a
+ * global load, 0.9-1.3 us. */
+#define INTRA_RING_STAGE_UINT4 (2 * INTRA_CW_MAX * 32)
+template <int NJ>
+DEVFN void intra_loader(const int *recs, uint4 *ring, int mbw, int cb, int nr, int steps, int lt0, int nload, int lane) {
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int u0 = lt0 + j * nload, u = u0 + lane, row = u >> 5, mxx = t - row;
+            const bool ok = row < nr && mxx >= 0 && mxx < mbw;
+            const uint4 *src = ok ? (const uint4 *)(recs + ((size_t)(cb + row) * mbw + mxx) * INTRA_REC_DWORDS) + (u & 31) : (const uint4 *)recs;
+            uint4 *dst = ring + (t & 3) * INTRA_RING_STAGE_UINT4 + u0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+        }
+    };
+    constexpr int n = 2 * NJ; /* s_waitcnt immediate: vmcnt in bits 3:0 (and 15:14), expcnt and lgkmcnt left at their maxima */
+    fetch(0);
+    fetch(1);
+    fetch(2);
+    __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8));
+    __builtin_amdgcn_s_barrier();
+    for (int step = 0; step < steps; step++) {
+        fetch(step + 3);
+        __builtin_amdgcn_s_waitcnt((n & 15) | (7 << 4) | (15 << 8));
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (15 << 8));
+}
+
 __global__ __launch_bounds__(1024) void k_intra_dc(venc_geom g, venc_bufs B, venc_step S, int cw) {
     __shared__ int s_bot[2 * INTRA_CW_MAX][4][5];
     __shared__ int s_last[INTRA_MAX_MBW][5]; /* bottom sums of the last row of the previous pass */
-    __shared__ uint4 s_ring[2][2 * INTRA_CW_MAX][INTRA_REC_DWORDS / 4];
+    __shared__ uint4 s_ring[4][2 * INTRA_CW_MAX][INTRA_REC_DWORDS / 4];
     const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
     const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
     const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
     const int *recs = B.intra_rec + (size_t)item * g.nmb * INTRA_REC_DWORDS;
 
     if (wv >= cw) {
-        /* ---- loader waves: records of step t go to ring stage t & 1 during step t - 1, fetched during step t - 2 */
-        const int nload = (int)blockDim.x - 64 * cw, lt = tid - 64 * cw;
+        /* ---- loader waves (intra_loader above) */
+        const int nload = (int)blockDim.x - 64 * cw, lt0 = (tid - 64 * cw) & ~63;
         for (int cb = r0; cb < r1; cb += 2 * cw) {
             const int nr = min(2 * cw, r1 - cb), steps = g.mbw + nr - 1;
-            uint4 ld[3] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-#define INTRA_FETCH(t)                                                                                            \
-    _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                \
-        const int u = lt + j * nload, row = u >> 5, mxx = (t) - row;                                               \
-        if (row < nr && mxx >= 0 && mxx < g.mbw)                                                                   \
-            ld[j] = ((const uint4 *)(recs + ((size_t)(cb + row) * g.mbw + mxx) * INTRA_REC_DWORDS))[u & 31];       \
-    }
-#define INTRA_PUT(t)                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < 3; j++) {                                                                \
-        const int u = lt + j * nload, row = u >> 5, mxx = (t) - row;                                               \
-        if (row < nr && mxx >= 0 && mxx < g.mbw) s_ring[(t) & 1][row][u & 31] = ld[j];                             \
-    }
-            INTRA_FETCH(0)
-            INTRA_PUT(0)
-            INTRA_FETCH(1)
-            lds_barrier();
-            for (int step = 0; step < steps; step++) {
-                INTRA_PUT(step + 1)
-                INTRA_FETCH(step + 2)
-                lds_barrier();
-            }
+            /* fetches of this wave per step: its j-th run of 64 units starts at lt0 + j * nload (wave-uniform) */
+            int nj = 0;
+            for (int j = 0; j < 3; j++) nj += lt0 + j * nload < nr * 32 ? 1 : 0;
+            uint4 *ring = &s_ring[0][0][0];
+            if (nj == 0) {
+                for (int k = 0; k < steps + 1; k++) __builtin_amdgcn_s_barrier();
+            } else if (nj == 1)
+                intra_loader<1>(recs, ring, g.mbw, cb, nr, steps, lt0, nload, lane);
+            else if (nj == 2)
+                intra_loader<2>(recs, ring, g.mbw, cb, nr, steps, lt0, nload, lane);
+            else
+                intra_loader<3>(recs, ring, g.mbw, cb, nr, steps, lt0, nload, lane);
             __syncthreads();
         }
         return;
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(1024) void k_intra_dc(venc_geom g, venc_bufs B, ven
         for (int step = 0; step < steps; step++) {
             const int mx = step - rw;
             if (rw < nr && mx >= 0 && mx < g.mbw) {
-                const int *rg = (const int *)s_ring[step & 1][rw];
+                const int *rg = (const int *)s_ring[step & 3][rw];
                 const int wdc = rg[l32];
                 int4 er = make_int4(0, 0, 0, 0), eb = make_int4(0, 0, 0, 0);
                 if (es >= 0) {
