@@ -238,9 +238,9 @@ def test_intra_three_kernels_equal_the_wavefront_kernel(venc, w, h, qp, slices, 
 
 
 @pytest.mark.gpu
-def test_cu_masked_entropy_stream_changes_nothing(venc, monkeypatch):
-    """VENC_ENTROPY_CUS (the entropy chain's stream confined to a subset of the CUs, an experiment kept behind an
-    environment variable) must not change the stream."""
+def test_placement_knobs_change_nothing(venc, monkeypatch):
+    """VENC_ENTROPY_CUS (the entropy chain's stream confined to a subset of the CUs) and VENC_ME_XCD (XCD-aware tile order
+    of the motion search), experiments kept behind environment variables, must not change the stream."""
     import torch
     w, h, n, keyint = 352, 288, 8, 4
     fb = w * h * 3 // 2
@@ -250,6 +250,7 @@ def test_cu_masked_entropy_stream_changes_nothing(venc, monkeypatch):
     for cus in (None, "64"):
         if cus:
             monkeypatch.setenv("VENC_ENTROPY_CUS", cus)
+            monkeypatch.setenv("VENC_ME_XCD", "1")
         e = venc.X264Encoder(w, h, qp=28, slices=4, keyint=keyint, gop_batch=2)
         got = []
         assert e.encode_resident(buf.data_ptr(), fb, n, lambda payload, nals, pts, key: got.append(payload)) == n

@@ -69,6 +69,7 @@ struct venc_ctx {
     uint16_t *d_rank, *d_cand;
     int intra_waves;
     int unit_phase;   /* which of the two unit counters the next P step fills */
+    int me_xcd;       /* VENC_ME_XCD=1: XCD-aware tile order in k_me_pool (less fabric traffic, slightly slower) */
     int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
     int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
     int max_slice_mbs;
@@ -353,6 +354,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
     c->me_stop = getenv("VENC_ME_STOP") ? atoi(getenv("VENC_ME_STOP")) : 0;
+    c->me_xcd = getenv("VENC_ME_XCD") && atoi(getenv("VENC_ME_XCD")) != 0;
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
@@ -538,8 +540,15 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_me_tile, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
                                s1, g, b, S);
         else
-            hipLaunchKernelGGL(k_me_pool, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
-                               s1, g, b, S);
+        {
+            const int ntx = (g.mbw + T2_MBX - 1) / T2_MBX, nty = (band_rows + T2_MBY - 1) / T2_MBY;
+            /* raster order, or (VENC_ME_XCD=1) runs of 64 tiles dealt to the XCDs in rotation: grid.x is then the picture's
+             * tile count padded to whole rounds of eight runs (see k_me_pool) */
+            const int runs = (ntx * nty + 63) / 64;
+            const uint32_t tx_magic = ntx > 1 ? (uint32_t)((0x100000000ull + (uint64_t)ntx - 1) / (uint64_t)ntx) : 0u;
+            const int gx = c->me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
+            hipLaunchKernelGGL(k_me_pool, dim3(gx, 1, n_items), dim3(512), 0, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd);
+        }
         prof_end(c, s1);
         const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */
         if (flags_mbs) {

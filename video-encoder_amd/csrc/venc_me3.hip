@@ -77,7 +77,7 @@ DEVFN uint32_t me3_quarter_sad(const uint32_t *s_win, const uint32_t *s_cur, int
     return a;
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_me_pool(venc_geom g, venc_bufs B, venc_step S) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_me_pool(venc_geom g, venc_bufs B, venc_step S, int tiles_x, int tiles_y, uint32_t tx_magic, int xcd_runs) {
     __shared__ __attribute__((aligned(16))) uint32_t s_win[T2_WR * T2_WD];
     __shared__ __attribute__((aligned(16))) uint32_t s_cur[T2_MBY * 16 * T3_CW];
     /* horizontal sums (P1 -> P2), then, after a barrier, the vertical pairs built from them (P2 -> P3) */
@@ -99,7 +99,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
     const int col0 = mbx * 16, row0 = mby * 16;
     const uint16_t *rank = s_rank;
-    const int item = blockIdx.z, tx = blockIdx.x, ty = blockIdx.y;
+    /* Tile order.  Default: raster order over the picture (grid.x = tiles of a picture).  Workgroups are dealt
+     * round-robin to the 8 XCDs (b and b + 8 share one, each XCD has its own 4 MB L2), so in raster order the tiles that
+     * share a window halo -- left/right and upper/lower neighbours -- sit on different XCDs and every halo crosses the
+     * fabric again: rocprofv3's FETCH_SIZE shows 2.5x the algorithmic bytes.  xcd_runs != 0 (VENC_ME_XCD=1) cuts the
+     * raster order into runs of 64 tiles that go to the XCDs in rotation (grid.x is then a multiple of 8 and
+     * blockIdx.x & 7 labels the XCD): the traffic falls to 1.03-1.14x the algorithmic bytes -- and the kernel gets 1-5 %
+     * SLOWER at 1080p (neutral at 2160p), whether an XCD gets one contiguous eighth of the launch, strips of four tile
+     * rows or runs of 64 tiles.  The kernel is bound by VALU and LDS, not by these fetches (which the 256 MB last-level
+     * cache serves), and neighbours on one XCD pull the same L2 lines at the same time.  Hence off by default; kept for
+     * memory-bound company.  Placement is never a correctness matter. */
+    const int item = blockIdx.z;
+    const int kx = (int)(blockIdx.x >> 3);
+    const int tile = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
+    if (tile >= tiles_x * tiles_y) return;
+    /* tx_magic = ceil(2^32 / tiles_x), exact for these sizes; 0 stands for tiles_x == 1 (2^32 does not fit) */
+    const int ty = tx_magic ? (int)__umulhi((uint32_t)tile, tx_magic) : tile, tx = tile - ty * tiles_x;
     const int x0 = tx * T2_MBX * 16, y0 = (S.row0 + ty * T2_MBY) * 16;
     const int mx = tx * T2_MBX + mbx, my = S.row0 + ty * T2_MBY + mby;
     const bool mb_valid = mx < g.mbw && my < S.row1;
