@@ -77,8 +77,8 @@ def cpu_baseline(wl, frames, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
     ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip); 300 = the whole clip, ~15 s on 16 cores")
