@@ -158,6 +158,8 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.mboff);
     (void)hipFree(c->b.codedmask);
     (void)hipFree(c->b.unit_list);
+    (void)hipFree(c->b.slice_bits);
+    (void)hipFree(c->b.scan_done);
     (void)hipFree(c->b.unit_count);
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
@@ -339,6 +341,9 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.codedmask, G * ((nmb + 63) / 64) * 8));
     OPEN_OK(hipMalloc(&b.unit_list, G * nmb * 7 * 4));
+    OPEN_OK(hipMalloc(&b.slice_bits, G * VENC_MAX_SLICES * 4));
+    OPEN_OK(hipMalloc(&b.scan_done, G * VENC_COUNTER_STRIDE * 4));
+    OPEN_OK(hipMemset(b.scan_done, 0, G * VENC_COUNTER_STRIDE * 4));
     OPEN_OK(hipMalloc(&b.unit_count, 2 * G * VENC_COUNTER_STRIDE * 4));
     OPEN_OK(hipMemset(b.unit_count, 0, 2 * G * VENC_COUNTER_STRIDE * 4));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
@@ -595,7 +600,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         c->side_step[rs] = c->step_no;
     }
     prof_begin(c, KID_SCAN, s2);
-    hipLaunchKernelGGL(k_scan, dim3(n_items), dim3(1024), 0, s2, g, b, S, c->d_slice);
+    hipLaunchKernelGGL(k_scan, dim3(band_slices, n_items), dim3(64 * SCAN_WAVES), 0, s2, g, b, S, c->d_slice);
     prof_end(c, s2);
     prof_begin(c, KID_PACK, s2);
     hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, band_slices, n_items), dim3(256), 0, s2, g, b, S,

@@ -96,6 +96,8 @@ typedef struct {
     uint32_t *unit_list;        /* [G][nmb * 7] P pictures: non-empty syntax units, mb << 3 | unit (k_skip -> k_cavlc_p) */
     uint32_t *unit_count;       /* [G][32] (one per 128-byte line) entries of unit_list; two counters alternate between P steps (the launcher sets both pointers) */
     uint32_t *unit_count_next;
+    uint32_t *slice_bits;       /* [G][VENC_MAX_SLICES] bits of every slice of the step (k_scan: per-slice blocks -> the block that builds the table) */
+    uint32_t *scan_done;        /* [G][32] k_scan arrival counters, one cache line each; zero between launches */
     const int *slice_first_row; /* n_slices + 1 */
     const uint8_t *row_slice;   /* mbh */
     const uint16_t *me_rank;    /* [33*33] candidate (dyi*33+dxi) -> rank */
