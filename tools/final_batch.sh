@@ -14,10 +14,10 @@ done
 cd $R
 for wl in 1080p 2160p; do python3 tools/pmc_summary.py $O/pmcf_$wl $O/pmcw_$wl $wl > /dev/null; done
 cp profiles/pmc_traffic.json $O/
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 > $O/bench_1080p.json 2> $O/bench_1080p.err; cut -c1-240 $O/bench_1080p.json
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --workload 2160p --cpu-frames 0 > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --serial-steps --cpu-frames 0 > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --serial-steps --workload 2160p --cpu-frames 0 > $O/bench_2160p_serial.json 2> $O/bench_2160p_serial.err
+timeout -k 10 300 python bench.py > $O/bench_1080p.json 2> $O/bench_1080p.err; cut -c1-240 $O/bench_1080p.json
+timeout -k 10 300 python bench.py --workload 2160p --cpu-frames 0 > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
+timeout -k 10 300 python bench.py --serial-steps --cpu-frames 0 > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
+timeout -k 10 300 python bench.py --serial-steps --workload 2160p --cpu-frames 0 > $O/bench_2160p_serial.json 2> $O/bench_2160p_serial.err
 cd /tmp
 for wl in 1080p 2160p; do
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --cpu-frames 0 > $O/stats_$wl.log 2>&1
