@@ -57,6 +57,7 @@ struct venc_ctx {
     long long side_step[VENC_RING];  /* step whose entropy chain recorded ev_side[slot] (-1: none) */
     int overlap;
     hipEvent_t ev[VENC_EVENTS];
+    int ev_done; /* newest ticket known to be complete (-1: none) */
     int ev_next;
     int parity;
     long long step_no; /* steps issued so far; ring slot of a step = step_no % VENC_RING */
@@ -273,6 +274,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         c->side_step[i] = -1;
     }
     c->overlap = !(getenv("VENC_NO_OVERLAP") && atoi(getenv("VENC_NO_OVERLAP")) != 0);
+    c->ev_done = -1;
 
     /* slice bands: the first (mbh % n) bands get one extra MB row */
     int rows[VENC_MAX_SLICES + 1];
@@ -720,7 +722,11 @@ extern "C" int venc_wait(venc_ctx *c, int ticket) {
         SET_ERR("venc_wait: stale ticket %d", ticket);
         return -1;
     }
+    /* tickets complete in order (one stream records them): the frames of a step share a ticket, and a later ticket
+     * that has been waited for covers the earlier ones -- no second trip into the runtime for them */
+    if (ticket <= c->ev_done) return 0;
     HIP_OK(hipEventSynchronize(c->ev[ticket % VENC_EVENTS]));
+    c->ev_done = ticket;
     return 0;
 }
 extern "C" int venc_sync(venc_ctx *c) {
