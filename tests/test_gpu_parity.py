@@ -76,6 +76,10 @@ def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x
     (130, 258, 36, 5, 3, 4, "noise"),      # 9 x 17 macroblocks: ragged right and bottom tiles, uneven slices
     (176, 464, 28, 1, 2, 3, "noise"),      # 29 MB rows in one slice: two passes of the intra DC chain (24 + 5 rows)
     (7680, 4320, 32, 8, 2, 2, "synth"),    # 8K: 480 x 270 macroblocks, 34-row slices (two passes of the intra DC chain), 60 tiles per row
+    (1280, 720, 30, 45, 3, 3, "synth"),    # one slice per macroblock row: 45 blocks per item in k_scan, the last one writes the table
+    (16, 256, 28, 4, 3, 4, "noise"),       # one macroblock wide: single-column wavefront, every search window piece left/right outside
+    (352, 288, 51, 3, 3, 4, "synth"),      # maximum QP on smooth content: nearly everything P_Skip, long skip runs across slices
+    (1920, 1088, 20, 8, 2, 2, "synth"),    # low QP (dense residual: every syntax unit of most macroblocks listed)
 ])
 def test_stages_match_oracle(venc, orc, w, h, qp, slices, keyint, n, kind):
     _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind)
