@@ -182,10 +182,14 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     bytes_per_step = int(tally.bytes) // (args.steps if pipelined else 1) if tally else None
+    bytes_timed = int(tally.bytes) if tally else None
     prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
     barrier()
     if pipelined:
         tally = one_pass()  # untimed: the digest of ONE pass, comparable across runs whatever --steps was
+        if bytes_timed != args.steps * int(tally.bytes):  # every pass of the timed stream must have produced this pass's bytes
+            raise SystemExit("bench: the %d timed passes produced %d bytes, %d x one pass = %d" % (
+                args.steps, bytes_timed, args.steps, args.steps * int(tally.bytes)))
         if not args.no_profile:
             enc.profile_read()
         barrier()
