@@ -12,9 +12,40 @@
  * coded_block_pattern go to separate bytes of the macroblock record (they are written concurrently).
  */
 
+/* Byte k of a packed dword as an operand, without unpacking it first (SDWA source selects; the compiler's own SDWA
+ * peephole leaves these unpacks alone): cur - pred and pred + residual straight from the loaded dwords save 32 of the
+ * ~450 instructions of a luma lane. */
+template <int K>
+DEVFN int byte_sub_byte(uint32_t a, uint32_t b) { /* a.byte[K] - b.byte[K] */
+    int r;
+    if (K == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 1) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 2) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 3) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int K>
+DEVFN int byte_sub_int(uint32_t a, int b) { /* a.byte[K] - b */
+    int r;
+    if (K == 0) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 1) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 2) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 3) asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <int K>
+DEVFN int int_add_byte(int a, uint32_t b) { /* a + b.byte[K] */
+    int r;
+    if (K == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(b));
+    if (K == 3) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+/* quantisation, dequantisation and inverse transform of one 4x4 block: levels (scan order) and the residual rr */
 template <bool DC_SEP>
-DEVFN void blk_quant_recon(const int w[16], const venc_qparams &q, int f, int d0, const int pred[16], int lv[16], int rec[16],
-                           int &nnz) {
+DEVFN void blk_quant_res(const int w[16], const venc_qparams &q, int f, int d0, int lv[16], int rr[16], int &nnz) {
     int d[16];
     nnz = 0;
     /* sign(w) * ((|w| mf + f) >> s) without the magnitude: for w < 0 it equals (w mf + 2^s - 1 - f) >> s with an
@@ -35,10 +66,21 @@ DEVFN void blk_quant_recon(const int w[16], const venc_qparams &q, int f, int d0
         d[r] = VENC_MUL24(l, cls == 0 ? vs0 : cls == 1 ? vs1 : vs2); /* |l| < 2^16 */
     }
     if (DC_SEP) d[0] = d0;
-    int rr[16];
     venc_idct4(d, rr);
+}
+/* four rows of a current 4x4 block as packed dwords (aligned loads inside the display area, clamped bytes on its edges) */
+DEVFN void load_cur4x4_pk(const uint8_t *cur, int cstride, int pw, int ph, int px, int py, bool aligned, uint32_t cq[4]) {
+    if (aligned && px + 4 <= pw && py + 4 <= ph) {
 #pragma unroll
-    for (int i = 0; i < 16; i++) rec[i] = venc_clip_u8(pred[i] + rr[i]);
+        for (int y = 0; y < 4; y++) cq[y] = *(const uint32_t *)(cur + (size_t)(py + y) * cstride + px);
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint8_t *row = cur + (size_t)min(py + y, ph - 1) * cstride;
+            cq[y] = (uint32_t)row[min(px, pw - 1)] | ((uint32_t)row[min(px + 1, pw - 1)] << 8) | ((uint32_t)row[min(px + 2, pw - 1)] << 16) |
+                    ((uint32_t)row[min(px + 3, pw - 1)] << 24);
+        }
+    }
 }
 
 DEVFN void store_levels(int16_t *dst16, const int lv[16]) {
@@ -60,17 +102,6 @@ DEVFN void unpack4(uint32_t v, int *o) {
     o[0] = (int)(v & 255u), o[1] = (int)((v >> 8) & 255u), o[2] = (int)((v >> 16) & 255u), o[3] = (int)(v >> 24);
 }
 /* current 4x4 block: aligned dword rows inside the display area, clamped bytes on its edges */
-DEVFN void load_cur4x4(const uint8_t *cur, int cstride, int pw, int ph, int px, int py, bool aligned, int c[16]) {
-    if (aligned && px + 4 <= pw && py + 4 <= ph) {
-#pragma unroll
-        for (int y = 0; y < 4; y++) unpack4(*(const uint32_t *)(cur + (size_t)(py + y) * cstride + px), c + 4 * y);
-    } else {
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
-    }
-}
 
 /* luma transform of macroblock mb with vector (dx, dy): 16 lanes, lane & 15 = luma4x4BlkIdx, lane & 48 = the
  * wave's group of 16; every lane of the wave calls this (ballots), `valid` guards the stores */
@@ -83,8 +114,8 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
     const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
     uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
 
-    int c[16], p[16];
-    load_cur4x4(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, c);
+    uint32_t cq[4], pq[4]; /* current and predicted rows, four samples per dword */
+    load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, cq);
     const int x0 = px + dx, y0 = py + dy;
     if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
         const uint32_t sh = (uint32_t)(x0 & 3);
@@ -92,20 +123,33 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
 #pragma unroll
         for (int y = 0; y < 4; y++) {
             const uint32_t *r32 = (const uint32_t *)(rp + (size_t)y * rstride);
-            unpack4(__builtin_amdgcn_alignbyte(r32[1], r32[0], sh), p + 4 * y);
+            pq[y] = __builtin_amdgcn_alignbyte(r32[1], r32[0], sh);
         }
     } else {
 #pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                p[4 * y + x] = ref[(size_t)clampi(y0 + y, 0, g.ch - 1) * rstride + clampi(x0 + x, 0, g.cw - 1)];
+        for (int y = 0; y < 4; y++) {
+            const uint8_t *row = ref + (size_t)clampi(y0 + y, 0, g.ch - 1) * rstride;
+            pq[y] = (uint32_t)row[clampi(x0, 0, g.cw - 1)] | ((uint32_t)row[clampi(x0 + 1, 0, g.cw - 1)] << 8) |
+                    ((uint32_t)row[clampi(x0 + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(x0 + 3, 0, g.cw - 1)] << 24);
+        }
     }
     int res[16], w[16], lv[16], rr[16], nnz;
 #pragma unroll
-    for (int i = 0; i < 16; i++) res[i] = c[i] - p[i];
+    for (int y = 0; y < 4; y++) {
+        res[4 * y] = byte_sub_byte<0>(cq[y], pq[y]);
+        res[4 * y + 1] = byte_sub_byte<1>(cq[y], pq[y]);
+        res[4 * y + 2] = byte_sub_byte<2>(cq[y], pq[y]);
+        res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
+    }
     venc_fdct4(res, w);
-    blk_quant_recon<false>(w, g.ql, g.ql.f_inter, 0, p, lv, rr, nnz);
+    blk_quant_res<false>(w, g.ql, g.ql.f_inter, 0, lv, rr, nnz);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        rr[4 * y] = venc_clip_u8(int_add_byte<0>(rr[4 * y], pq[y]));
+        rr[4 * y + 1] = venc_clip_u8(int_add_byte<1>(rr[4 * y + 1], pq[y]));
+        rr[4 * y + 2] = venc_clip_u8(int_add_byte<2>(rr[4 * y + 2], pq[y]));
+        rr[4 * y + 3] = venc_clip_u8(int_add_byte<3>(rr[4 * y + 3], pq[y]));
+    }
 
     int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
@@ -137,44 +181,62 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
     uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
     const int rw = g.cw >> 1, rh = g.ch >> 1;
 
-    int c[16], p[16];
-    load_cur4x4(cur, cstride, pw, ph, px, py, (g.w & 7) == 0, c);
+    int p[16];
+    uint32_t cq[4];
+    load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 7) == 0, cq);
     /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
     const int x0 = px + (dx >> 1), y0 = py + (dy >> 1);
-    const int xf = (dx & 1) * 4, yf = (dy & 1) * 4;
-    int smp[5][5];
+    const bool fx = (dx & 1) != 0, fy = (dy & 1) != 0;
+    /* rows of the reference as packed samples: ra[y] = samples x0..x0+3, rb[y] = x0+1..x0+4 */
+    uint32_t ra[5], rb[5];
     if (x0 >= 0 && x0 + 8 <= rw && y0 >= 0 && y0 + 5 <= rh) {
-        const uint32_t sh = (uint32_t)(x0 & 3);
+        const uint32_t sh8 = (uint32_t)(x0 & 3) * 8u;
         const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
 #pragma unroll
         for (int y = 0; y < 5; y++) {
             const uint32_t *r32 = (const uint32_t *)(rp + (size_t)y * rstride);
-            const uint32_t d0 = r32[0], d1 = r32[1];
-            unpack4(__builtin_amdgcn_alignbyte(d1, d0, sh), smp[y]);
-            smp[y][4] = (int)(__builtin_amdgcn_alignbyte(0u, d1, sh) & 255u);
+            const uint64_t two = ((uint64_t)r32[1] << 32) | r32[0];
+            ra[y] = (uint32_t)(two >> sh8);
+            rb[y] = (uint32_t)(two >> (sh8 + 8u)); /* shift <= 32: the fifth sample is byte 3 of the upper dword at most */
         }
     } else {
 #pragma unroll
-        for (int y = 0; y < 5; y++)
+        for (int y = 0; y < 5; y++) {
+            const uint8_t *row = ref + (size_t)clampi(y0 + y, 0, rh - 1) * rstride;
+            uint32_t s5[5];
 #pragma unroll
-            for (int x = 0; x < 5; x++) smp[y][x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
+            for (int x = 0; x < 5; x++) s5[x] = row[clampi(x0 + x, 0, rw - 1)];
+            ra[y] = s5[0] | (s5[1] << 8) | (s5[2] << 16) | (s5[3] << 24);
+            rb[y] = s5[1] | (s5[2] << 8) | (s5[3] << 16) | (s5[4] << 24);
+        }
     }
     /* 8.4.2.2.2 with fractions in {0, 4}: ((8-xf)(8-yf) A + xf (8-yf) B + (8-xf) yf C + xf yf D + 32) >> 6 is A, (A+B+1)>>1,
-     * (A+C+1)>>1 or (A+B+C+D+2)>>2 -- in every case (A + X + Y + Z + 2) >> 2 with X, Y, Z picked among A, B, C, D.  Three
-     * selects and four adds per sample instead of four quarter-rate 32-bit multiplies. */
-    const bool fx = xf != 0, fy = yf != 0;
+     * (A+C+1)>>1 or (A+B+C+D+2)>>2 -- in every case (h(y) + (fy ? h(y+1) : h(y)) + 2) >> 2 with the horizontal pair sum
+     * h = A + (fx ? B : A).  The pair sums come straight from the packed rows (one select per ROW between the row and the
+     * row one sample on, then byte-select adds); one select, one three-operand add and a shift per sample remain.  No
+     * quarter-rate multiplies, no unpacking. */
+    int hs[5][4];
+#pragma unroll
+    for (int y = 0; y < 5; y++) {
+        const uint32_t rs = fx ? rb[y] : ra[y];
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(hs[y][0]) : "v"(ra[y]), "v"(rs));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(hs[y][1]) : "v"(ra[y]), "v"(rs));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(hs[y][2]) : "v"(ra[y]), "v"(rs));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(hs[y][3]) : "v"(ra[y]), "v"(rs));
+    }
 #pragma unroll
     for (int y = 0; y < 4; y++)
 #pragma unroll
-        for (int x = 0; x < 4; x++) {
-            const int A = smp[y][x], Bv = smp[y][x + 1], Cv = smp[y + 1][x], Dv = smp[y + 1][x + 1];
-            const int X = fx ? Bv : A, Y = fy ? Cv : A, Z = fx ? (fy ? Dv : Bv) : (fy ? Cv : A);
-            p[4 * y + x] = (A + X + Y + Z + 2) >> 2;
-        }
+        for (int x = 0; x < 4; x++) p[4 * y + x] = (hs[y][x] + (fy ? hs[y + 1][x] : hs[y][x]) + 2) >> 2;
 
     int res[16], w[16], lv[16], rr[16], nnz;
 #pragma unroll
-    for (int i = 0; i < 16; i++) res[i] = c[i] - p[i];
+    for (int y = 0; y < 4; y++) {
+        res[4 * y] = byte_sub_int<0>(cq[y], p[4 * y]);
+        res[4 * y + 1] = byte_sub_int<1>(cq[y], p[4 * y + 1]);
+        res[4 * y + 2] = byte_sub_int<2>(cq[y], p[4 * y + 2]);
+        res[4 * y + 3] = byte_sub_int<3>(cq[y], p[4 * y + 3]);
+    }
     venc_fdct4(res, w);
     /* 2x2 DC transform over the four lanes of the plane */
     int yc = 0;
@@ -190,7 +252,9 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
         const int v = __shfl(dclv, qbase | qi);
         fc += (__popc(k & qi) & 1) ? -v : v;
     }
-    blk_quant_recon<true>(w, g.qc, g.qc.f_inter, venc_dequant_chroma_dc(fc, &g.qc), p, lv, rr, nnz);
+    blk_quant_res<true>(w, g.qc, g.qc.f_inter, venc_dequant_chroma_dc(fc, &g.qc), lv, rr, nnz);
+#pragma unroll
+    for (int i = 0; i < 16; i++) rr[i] = venc_clip_u8(p[i] + rr[i]);
 
     int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
