@@ -11,6 +11,19 @@ the reference hands it to its muxer).  Timed region = kernels + write-out of the
 slice RBSPs into pinned host memory + host-side NAL packaging (emulation
 prevention, length prefixes) of every frame.
 
+The metric names "1080p & 4K" and "bit-exact vs CPU ref", so the ONE JSON line of the default run carries, besides the
+1080p headline:
+  "2160p"           the same measurement on BASELINE config 3 (value, ms_per_step, roofline)
+  "bit_exact"       SHA-256 of the HIP bitstream of one untimed pass against the SHA-256 of the CPU oracle's bitstream
+                    of the same frames (all 300 at 1080p; the first 60 at 2160p); a mismatch exits non-zero
+  "pcie_inclusive"  host frames (pinned memory) through x264_encoder_encode -- the call the reference makes
+                    (av_encode.c:970), with its H2D copy per frame -- never `value`
+  "cpu_baseline"    the CPU oracle on the box's host cores: all cores (<= 16 OpenMP threads) on the whole clip, and a
+                    one-thread line on one GOP; `cores` = threads used, `host_cores` = os.cpu_count()
+  "roofline"        dominant kernel (k_me) against the HBM-read roofline, from HIP events recorded on the engine's
+                    stream inside the timed region
+The CPU oracle is this repository's own C restatement (oracle/): NOT libx264; parity with libx264 is unpinned.
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank
 encodes its own clip (independent streams / closed GOPs shard with no data-path
 collective -- SURVEY.md section 8e, BASELINE config 4); value = pixels of all
@@ -18,18 +31,13 @@ ranks / max-over-ranks time; scaling = "weak".
 
 --mode slices (BASELINE config 5, e.g. --workload 2160p): ONE stream, every picture cut into the
 same 8 slices whatever N is, rank r codes a contiguous band of slices and the ranks swap
-reconstructed rows once per picture (RCCL all-gather on the engine's stream,
-video-encoder_amd/dist.py BandExchange); the bands' payloads are gathered on rank 0 and
+reconstructed rows once per picture; the bands' payloads are gathered on rank 0 and
 interleaved into the single-encoder bitstream inside the timed region; value = pixels of the
 one clip / max-over-ranks time; scaling = "strong".
-
-Extra objects in the JSON line:
-  roofline      dominant kernel (k_me) against the HBM-read roofline, from HIP
-                events recorded on the engine's stream inside the timed region
-  cpu_baseline  this repo's CPU oracle (kind "port": the reference's own path is
-                un-vendored libx264 and cannot be timed) on a bounded sample
 """
 import argparse
+import ctypes as C
+import hashlib
 import importlib
 import json
 import os
@@ -53,71 +61,111 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 ME_EVENT_STRIDE = 8             # timed region: HIP-event pairs around every 8th k_me launch (each pair stalls the stream ~8 us: 1 in 4 cost 3.6 % of a 1080p pass)
 ME_ALGO_BYTES_PER_PX = 2.0      # k_me reads cur Y (1.0) + ref Y (1.0) per P-frame pixel (DESIGN.md section 4)
+ORACLE_NOTE = "CPU oracle = this repo's own C restatement (oracle/), not libx264; parity with libx264 unpinned"
 
 
-def cpu_baseline(wl, frames, threads):
-    """CPU oracle (this repo's C restatement; NOT libx264) on the first `frames` frames of the same clip."""
-    import orc_py
-    venc = importlib.import_module("video-encoder_amd")
+def host_frames(wl, host):
+    """[(y, u, v)] views of frames copied back from the resident clip (host: uint8 array [n][w*h*3/2])."""
     w, h = wl["w"], wl["h"]
-    clip = [venc.synth_frame(w, h, t) for t in range(frames)]
-    enc = orc_py.Encoder(w, h, qp=wl["qp"], n_slices=wl["slices"], keyint=wl["keyint"], threads=threads)
+    return [(f[:w * h].reshape(h, w), f[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), f[w * h * 5 // 4:].reshape(h // 2, w // 2)) for f in host]
+
+
+def oracle_run(wl, clip, threads):
+    """The CPU oracle over `clip` (list of (y, u, v)): (seconds, sha256 of the concatenated payloads, bytes)."""
+    import orc_py
+    enc = orc_py.Encoder(wl["w"], wl["h"], qp=wl["qp"], n_slices=wl["slices"], keyint=wl["keyint"], fps=(30, 1), sar=(1, 1), threads=threads)
+    md, nbytes = hashlib.sha256(), 0
     t0 = time.perf_counter()
-    nbytes = 0
     for y, u, v in clip:
-        nbytes += len(enc.encode(y, u, v).data)
+        d = enc.encode(y, u, v).data
+        md.update(d)
+        nbytes += len(d)
     dt = time.perf_counter() - t0
     enc.close()
-    return dict(value=round(frames * w * h / dt / 1e6, 3), unit="Mpixels/s", cores=threads, kind="port",
-                sample="first %d frames (%d I + %d P, closed GOPs of %d) of the same %dx%d clip, %d OpenMP threads, %.1f s" % (
-                    frames, (frames + wl["keyint"] - 1) // wl["keyint"], frames - (frames + wl["keyint"] - 1) // wl["keyint"],
-                    wl["keyint"], w, h, threads, dt))
+    return dt, md.hexdigest(), nbytes
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
-    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the CPU baseline sample (0 = skip); 300 = the whole clip, ~15 s on 16 cores")
-    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    ap.add_argument("--serial-steps", action="store_true", help="one engine call per step (no overlap between consecutive steps)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
-    ap.add_argument("--mode", default="streams", choices=("streams", "slices"),
-                    help="streams: one clip per GPU, no collective (default); slices: one clip, slice bands across GPUs")
-    ap.add_argument("--halo", type=int, default=16, help="slices mode: luma rows exchanged per band edge (0 = whole bands)")
-    ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
-    args = ap.parse_args()
+def hip_digest(enc, clip_ptr, fb, frames, first):
+    """SHA-256 over the payloads of the first `first` frames of one untimed pass (Python sink), and their byte count."""
+    md, cnt = hashlib.sha256(), [0, 0]
 
-    import torch
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
-    if args.device >= 0:
-        local_rank = args.device
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    def sink(payload, nals, pts, key):
+        if cnt[0] < first:
+            md.update(payload)
+            cnt[1] += len(payload)
+        cnt[0] += 1
+    enc.encode_resident(clip_ptr, fb, frames, sink)
+    return md.hexdigest(), cnt[1]
 
-    venc = importlib.import_module("video-encoder_amd")
-    wl = WORKLOADS[args.workload]
+
+def pcie_inclusive(venc, torch, wl, clip, fb, gop_batch, device, passes=3):
+    """Host pictures through x264_encoder_encode (av_encode.c:970): the clip sits in pinned host memory, pic_in's plane
+    pointers walk through it (no fread, no host copy), every call uploads one frame (copy stream) and returns once the
+    picture may be reused; then the reference's flush loop (av_encode.c:1076-1083).  Whole job: pipeline fill and drain
+    included."""
+    w, h, frames, keyint = wl["w"], wl["h"], wl["frames"], wl["keyint"]
+    H, L = venc.hip_lib(), venc.x264_lib()
+    nbytes = frames * fb
+    hp = H.venc_host_alloc(nbytes)
+    if not hp:
+        return {"error": "pinned host allocation of %d bytes failed" % nbytes}
+    try:
+        host = torch.frombuffer((C.c_uint8 * nbytes).from_address(hp), dtype=torch.uint8)
+        host.copy_(clip.cpu())
+        enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1), gop_batch=gop_batch, device=device)
+        pic, pout = venc.X264Picture(), venc.X264Picture()
+        pic.img.i_csp, pic.img.i_plane = venc.X264_CSP_I420, 3
+        pic.img.i_stride[0], pic.img.i_stride[1], pic.img.i_stride[2] = w, w // 2, w // 2
+        nals, nn = C.POINTER(venc.X264Nal)(), C.c_int(0)
+        u8p = C.POINTER(C.c_uint8)
+
+        def run(n_passes):
+            out_frames = out_bytes = 0
+            for k in range(n_passes * frames):
+                base = hp + (k % frames) * fb
+                pic.img.plane[0] = C.cast(base, u8p)
+                pic.img.plane[1] = C.cast(base + w * h, u8p)
+                pic.img.plane[2] = C.cast(base + w * h * 5 // 4, u8p)
+                pic.i_pts = k
+                r = L.x264_encoder_encode(enc.h, C.byref(nals), C.byref(nn), C.byref(pic), C.byref(pout))
+                if r < 0:
+                    raise SystemExit("pcie_inclusive: x264_encoder_encode failed")
+                if r > 0:
+                    out_frames, out_bytes = out_frames + 1, out_bytes + r
+            while L.x264_encoder_delayed_frames(enc.h) > 0:
+                r = L.x264_encoder_encode(enc.h, C.byref(nals), C.byref(nn), None, C.byref(pout))
+                if r < 0:
+                    raise SystemExit("pcie_inclusive: flush failed")
+                if r > 0:
+                    out_frames, out_bytes = out_frames + 1, out_bytes + r
+            return out_frames, out_bytes
+        run(1)  # warm-up: pools, payload buffers
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nf, nb = run(passes)
+        dt = time.perf_counter() - t0
+        enc.close()
+        assert nf == passes * frames, (nf, passes * frames)
+        return {"value": round(nf * w * h / dt / 1e6, 2), "unit": "Mpixels/s", "ms_per_clip": round(dt / passes * 1e3, 3),
+                "bytes_per_clip": nb // passes, "h2d_GBps": round(nf * fb / dt / 1e9, 2),
+                "what": "%d passes of the %d-frame %dx%d clip from pinned host memory through x264_encoder_encode + the flush loop "
+                        "(one H2D copy per call on the copy stream, the call returns when the picture may be reused; gop_batch %d; "
+                        "pipeline fill and drain inside the timing)" % (passes, frames, w, h, gop_batch)}
+    finally:
+        H.venc_host_free(hp)
+
+
+def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_rank, want_digest_frames=0):
+    """One workload on this rank: the timed region of the contract + the untimed per-kernel passes.  Returns the fields
+    of the JSON line that depend on the workload (rank 0) or None."""
+    wl = WORKLOADS[wl_key]
     w, h, frames, keyint = wl["w"], wl["h"], wl["frames"], wl["keyint"]
     gop_batch = args.gop_batch or (frames + keyint - 1) // keyint
     fb = w * h * 3 // 2
+    slices_mode = args.mode == "slices"
 
     # synthetic clip, generated on the GPU straight into HBM (same bytes as the host generator)
     clip = torch.empty(frames * fb, dtype=torch.uint8, device="cuda")
-    slices_mode = args.mode == "slices"
     if venc.hip_lib().venc_synth_device(clip.data_ptr(), fb, w, h, 0, frames, 0x1234ABCD + (0 if slices_mode else rank)) != 0:
         raise SystemExit("venc_synth_device failed")
     torch.cuda.synchronize()
@@ -131,7 +179,7 @@ def main():
     enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
                            gop_batch=gop_batch, device=local_rank, **band_kw)
     if not args.no_profile:
-        enc.profile(True, capacity=8 * frames * max(2, args.steps, args.warmup))
+        enc.profile(True, capacity=8 * frames * max(2, steps, warmup))
         # timed region: HIP-event pairs around the dominant kernel only (each pair stalls the stream for a
         # few microseconds; pairs around all nine kernels of a step slowed the step by ~20 %).  The other
         # kernels are timed in the untimed passes below.
@@ -161,35 +209,35 @@ def main():
     # (x264_venc_encode_resident_loop): the GPU works on pass k + 1 while the host packages pass k and hands it to the
     # sink, as a server encoding batch after batch does; --serial-steps makes K separate calls, each of which returns only
     # after its last frame was delivered.  slices mode: separate calls (the exchange callback is per call).
-    pipelined = not slices_mode and not args.serial_steps and args.steps > 1
+    pipelined = not slices_mode and not args.serial_steps and steps > 1
     tally = None
-    if pipelined and args.warmup > 0:
+    if pipelined and warmup > 0:
         # the warm-up goes through the same call; at least two passes, so that both halves of the engine's
         # double-buffered output ring (and their host payload buffers) have been touched before the clock starts
-        enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=max(args.warmup, 2))
+        enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=max(warmup, 2))
     else:
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             tally = one_pass()
     if not args.no_profile:
         enc.profile_read()
     barrier()
     t0 = time.perf_counter()
     if pipelined:
-        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=args.steps)
+        tally = enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=steps)
     else:
-        for _ in range(args.steps):
+        for _ in range(steps):
             tally = one_pass()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    bytes_per_step = int(tally.bytes) // (args.steps if pipelined else 1) if tally else None
+    bytes_per_step = int(tally.bytes) // (steps if pipelined else 1) if tally else None
     bytes_timed = int(tally.bytes) if tally else None
     prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
     barrier()
     if pipelined:
         tally = one_pass()  # untimed: the digest of ONE pass, comparable across runs whatever --steps was
-        if bytes_timed != args.steps * int(tally.bytes):  # every pass of the timed stream must have produced this pass's bytes
+        if bytes_timed != steps * int(tally.bytes):  # every pass of the timed stream must have produced this pass's bytes
             raise SystemExit("bench: the %d timed passes produced %d bytes, %d x one pass = %d" % (
-                args.steps, bytes_timed, args.steps, args.steps * int(tally.bytes)))
+                steps, bytes_timed, steps, steps * int(tally.bytes)))
         if not args.no_profile:
             enc.profile_read()
         barrier()
@@ -207,26 +255,24 @@ def main():
             prof_iso, _ = enc.profile_read()
             enc.set_overlap(True)
     barrier()
+    digest, host = None, None
+    if want_digest_frames and rank == 0 and not slices_mode:
+        if not args.no_profile:
+            enc.profile(False)
+        digest = hip_digest(enc, clip.data_ptr(), fb, frames, want_digest_frames)
+        host = clip[:want_digest_frames * fb].cpu().numpy().reshape(want_digest_frames, fb)  # the oracle's input: the very same bytes
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    res = None
     if rank == 0:
-        px = (1 if slices_mode else world) * args.steps * frames * w * h
-        out = {
-            "metric": "Mpixels/s encoded at fixed QP, 1080p & 4K YUV420p; bit-exact vs CPU ref",
+        px = (1 if slices_mode else world) * steps * frames * w * h
+        res = {
             "value": round(px / dt / 1e6, 2),
-            "unit": "Mpixels/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "strong" if slices_mode else "weak",
-            "vs_baseline": None,
-            "dtype": "u8",
-            "data": "synthetic",
+            "ms_per_step": round(dt / steps * 1e3, 3),
+            "steps": steps, "warmup": warmup,
             "config": {"workload": wl["name"], "frames_per_step": frames, "gop_batch": gop_batch,
                        "parallelism": ("%d slice bands of one stream, %s exchange of reconstructed rows per picture (%s)" % (
                            world, "halo (%d luma rows per edge)" % args.halo if args.halo else "whole-band", args.backend))
@@ -234,18 +280,18 @@ def main():
                        "steps_pipelined": pipelined,
                        "bytes_per_step": bytes_per_step,
                        "bitstream_fnv1a": "%016x" % tally.fnv1a if tally else None,
-                       "cpu_oracle_note": "bit-exact vs this repo's CPU oracle (tests/); parity with libx264 unpinned"},
+                       "cpu_oracle_note": ORACLE_NOTE},
         }
+        if digest:
+            res["hip_sha256"], res["hip_sha256_frames"], res["hip_sha256_bytes"] = digest[0], want_digest_frames, digest[1]
         if slices_mode:
-            import hashlib
             whole = stream_info.get("frames", [])
-            out["config"]["bytes_per_step"] = sum(len(f) for f in whole)
-            out["config"]["bitstream_sha256"] = hashlib.sha256(b"".join(whole)).hexdigest()
-            out["config"]["exchanges_per_step"] = xc.exchanges // max(1, args.steps + args.warmup)
-            out["config"].pop("bitstream_fnv1a", None)
+            res["config"]["bytes_per_step"] = sum(len(f) for f in whole)
+            res["config"]["bitstream_sha256"] = hashlib.sha256(b"".join(whole)).hexdigest()
+            res["config"]["exchanges_per_step"] = xc.exchanges // max(1, steps + warmup)
+            res["config"].pop("bitstream_fnv1a", None)
         if prof:
             me_ms, me_n = prof.get("k_me", (0.0, 0))
-            total_ms = sum(v[0] for v in prof.values())
             if me_n:
                 # P launches of one pass over the clip: every unit of gop_batch GOPs advances keyint - 1 P pictures in lock-step
                 n_gops = (frames + keyint - 1) // keyint
@@ -261,37 +307,148 @@ def main():
                 tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
                 if os.path.exists(tfile):
                     try:
-                        traffic = json.load(open(tfile)).get(args.workload, {}).get("k_me_hbm_bytes_per_launch")
+                        traffic = json.load(open(tfile)).get(wl_key, {}).get("k_me_hbm_bytes_per_launch")
                     except Exception:
                         traffic = None
-                out["roofline"] = {"bound": "hbm", "kernel": "k_me", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                res["roofline"] = {"bound": "hbm", "kernel": "k_me", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                    "algorithmic_bytes_per_launch": int(algo_bytes),
                                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": me_n, "launches_sampled_one_in": ME_EVENT_STRIDE,
                                    "search_positions_per_s": round(1089.0 * 256.0 * px_per_launch / 256.0 / avg_s, 1),
                                    "timed_region_runs_two_kernel_chains_concurrently": True,
                                    "events_dropped": dropped,
-                                   "note": "HBM is the bound this line is priced against; the kernel itself is VALU/LDS bound "
-                                           "(59 % of the VALU issue rate alone on the chip: profiles/r01_i_sq_counters_1080p_isolated.txt, DESIGN.md 4.1)"}
+                                   "note": "HBM is the bound this line is priced against; the kernel itself is VALU/LDS bound (DESIGN.md 4.1)"}
                 iso_ms, iso_n = prof_iso.get("k_me", (0.0, 0))
                 if iso_n:
                     iso_s = iso_ms / iso_n * 1e-3
-                    out["roofline"]["isolated_avg_launch_us"] = round(iso_s * 1e6, 2)
-                    out["roofline"]["isolated_achieved"] = round(algo_bytes / iso_s / 1e9, 2)
-                    out["roofline"]["isolated_frac"] = round(algo_bytes / iso_s / 1e9 / HBM_PEAK_GBS, 5)
+                    res["roofline"]["isolated_avg_launch_us"] = round(iso_s * 1e6, 2)
+                    res["roofline"]["isolated_achieved"] = round(algo_bytes / iso_s / 1e9, 2)
+                    res["roofline"]["isolated_frac"] = round(algo_bytes / iso_s / 1e9 / HBM_PEAK_GBS, 5)
             if prof_all:  # untimed pass, both chains concurrent as in the timed region, event pairs around every kernel
-                out["kernel_ms_per_step"] = {k: round(v[0], 3) for k, v in prof_all.items()}
-                out["kernel_ms_per_step"]["sum"] = round(sum(v[0] for v in prof_all.values()), 3)
+                res["kernel_ms_per_step"] = {k: round(v[0], 3) for k, v in prof_all.items()}
+                res["kernel_ms_per_step"]["sum"] = round(sum(v[0] for v in prof_all.values()), 3)
             else:
-                out["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]}
+                res["kernel_ms_per_step"] = {k: round(v[0] / steps, 3) for k, v in prof.items() if v[1]}
             if prof_iso:
-                out["kernel_ms_per_step_isolated"] = {k: round(v[0], 3) for k, v in prof_iso.items()}
-        if world == 1 and args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(wl, min(args.cpu_frames, frames), min(os.cpu_count() or 1, 16))
-        print(json.dumps(out))
+                res["kernel_ms_per_step_isolated"] = {k: round(v[0], 3) for k, v in prof_iso.items()}
     enc.close()
+    extras = {}
+    if rank == 0 and world == 1 and not slices_mode and args.pcie and wl_key == args.workload:
+        extras["pcie_inclusive"] = pcie_inclusive(venc, torch, wl, clip, fb, gop_batch, local_rank)
+    del clip
+    torch.cuda.empty_cache()
+    return res, extras, host
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
+    ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
+    ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the all-cores CPU baseline sample, which is also the bit-exact check (0 = skip both); 300 = the whole clip, ~12 s on 16 cores")
+    ap.add_argument("--no-extras", action="store_true", help="headline workload only: no 2160p object, no PCIe-inclusive leg (profiling runs)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    ap.add_argument("--serial-steps", action="store_true", help="one engine call per step (no overlap between consecutive steps)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--mode", default="streams", choices=("streams", "slices"),
+                    help="streams: one clip per GPU, no collective (default); slices: one clip, slice bands across GPUs")
+    ap.add_argument("--halo", type=int, default=16, help="slices mode: luma rows exchanged per band edge (0 = whole bands)")
+    ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if args.device >= 0:
+        local_rank = args.device
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+
+    venc = importlib.import_module("video-encoder_amd")
+    slices_mode = args.mode == "slices"
+    solo = world == 1 and not slices_mode
+    extras_on = solo and not args.no_extras and args.workload == "1080p"
+    args.pcie = solo and not args.no_extras
+    check = solo and args.cpu_frames > 0
+    wl = WORKLOADS[args.workload]
+
+    res, extras, host = measure(args, torch, dist, venc, args.workload, args.steps, args.warmup, rank, world, local_rank,
+                          want_digest_frames=min(args.cpu_frames, wl["frames"]) if check else 0)
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mpixels/s encoded at fixed QP, 1080p & 4K YUV420p; bit-exact vs CPU ref",
+            "value": res["value"],
+            "unit": "Mpixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "strong" if slices_mode else "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": res["config"],
+        }
+        for k in ("roofline", "kernel_ms_per_step", "kernel_ms_per_step_isolated"):
+            if k in res:
+                out[k] = res[k]
+        out.update(extras)
+    bit_exact = {}
+    if extras_on:
+        # BASELINE config 3 in the same invocation: the metric names both sizes.  Fewer steps (a pass is ~4x longer).
+        args.pcie = False
+        r2, _, host2 = measure(args, torch, dist, venc, "2160p", max(3, args.steps // 2), 2, rank, world, local_rank,
+                               want_digest_frames=60 if check else 0)
+        out["2160p"] = {k: r2[k] for k in ("value", "ms_per_step", "steps", "warmup", "roofline", "kernel_ms_per_step", "config") if k in r2}
+        out["2160p"]["unit"] = "Mpixels/s"
+        if check:
+            wl2 = WORKLOADS["2160p"]
+            dt2, sha2, nb2 = oracle_run(wl2, host_frames(wl2, host2), min(os.cpu_count() or 1, 16))
+            del host2
+            bit_exact["2160p"] = {"frames": 60, "hip_sha256": r2.get("hip_sha256"), "oracle_sha256": sha2, "bytes": nb2,
+                                  "equal": r2.get("hip_sha256") == sha2 and r2.get("hip_sha256_bytes") == nb2}
+    if check and rank == 0:
+        # all-cores CPU baseline on a bounded sample of the same workload = the oracle side of the bit-exact check
+        n = min(args.cpu_frames, wl["frames"])
+        threads = min(os.cpu_count() or 1, 16)
+        clip_h = host_frames(wl, host)
+        dt_c, sha_c, nb_c = oracle_run(wl, clip_h, threads)
+        n1 = min(wl["keyint"], n)  # one-thread line: one closed GOP
+        dt_1, _, _ = oracle_run(wl, clip_h[:n1], 1)
+        kf = (n + wl["keyint"] - 1) // wl["keyint"]
+        out["cpu_baseline"] = {
+            "value": round(n * wl["w"] * wl["h"] / dt_c / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": "port",
+            "sample": "first %d frames (%d I + %d P, closed GOPs of %d) of the same %dx%d clip, %d OpenMP threads, %.1f s" % (
+                n, kf, n - kf, wl["keyint"], wl["w"], wl["h"], threads, dt_c),
+            "one_thread": {"value": round(n1 * wl["w"] * wl["h"] / dt_1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                           "sample": "first %d frames (one closed GOP) of the same clip, 1 thread, %.1f s" % (n1, dt_1)},
+            "note": ORACLE_NOTE}
+        bit_exact[args.workload] = {"frames": n, "hip_sha256": res.get("hip_sha256"), "oracle_sha256": sha_c, "bytes": nb_c,
+                                    "equal": res.get("hip_sha256") == sha_c and res.get("hip_sha256_bytes") == nb_c}
+    if rank == 0:
+        if bit_exact:
+            out["bit_exact"] = all(v["equal"] for v in bit_exact.values())
+            out["bit_exact_detail"] = bit_exact
+        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and bit_exact and not out["bit_exact"]:
+        raise SystemExit("bench: the HIP bitstream differs from the CPU oracle's: %s" % json.dumps(bit_exact))
 
 
 if __name__ == "__main__":

@@ -25,6 +25,17 @@ def venc():
 
 
 @pytest.fixture(scope="session")
+def legacy_lib(venc):
+    """TEST-ONLY build of the launcher with the first-generation kernels compiled in (csrc/Makefile: libvenc_hip_legacy.so),
+    selected per engine by VENC_ME / VENC_INTER / VENC_INTRA.  Loaded RTLD_LOCAL beside the product library."""
+    import ctypes
+    path = os.path.join(venc.CSRC, "libvenc_hip_legacy.so")
+    if not os.path.exists(path):
+        venc.build()
+    return venc.bind_hip(ctypes.CDLL(path, mode=ctypes.RTLD_LOCAL))
+
+
+@pytest.fixture(scope="session")
 def orc():
     import orc_py
     orc_py.build()

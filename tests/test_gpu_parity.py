@@ -218,13 +218,13 @@ def test_resident_loop_equals_separate_calls(venc, gop_batch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,qp,slices", [(352, 288, 26, 4), (176, 144, 51, 2), (178, 146, 12, 3), (176, 464, 30, 1)])
-def test_intra_three_kernels_equal_the_wavefront_kernel(venc, w, h, qp, slices, monkeypatch):
+def test_intra_three_kernels_equal_the_wavefront_kernel(venc, legacy_lib, w, h, qp, slices, monkeypatch):
     """I pictures: transform / DC chain / reconstruction as three kernels (venc_intra2.hip) against the one-kernel
     wavefront k_intra (VENC_INTRA=legacy, read when an engine is opened): same reconstruction, levels and macroblock
     records.  QP 51 noise is the case that exposed the v_ashr_pk_u8_i32 selection."""
     frames = noise_frames(w, h, 4, 0x1234ABCD)
     monkeypatch.setenv("VENC_INTRA", "legacy")
-    ea = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2)
+    ea = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2, lib=legacy_lib)
     monkeypatch.delenv("VENC_INTRA")
     eb = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2)
     for t, (y, u, v) in enumerate(frames):
@@ -263,11 +263,11 @@ def test_placement_knobs_change_nothing(venc, monkeypatch):
     assert outs[0] == outs[1]
 
 
-def _me_run(venc, frames, w, h, mode):
+def _me_run(venc, frames, w, h, mode, lib=None):
     import os
     os.environ["VENC_ME"] = mode
     try:
-        eng = venc.Engine(w, h, qp=26, n_slices=4, max_items=1, in_slots=2, out_slots=2)
+        eng = venc.Engine(w, h, qp=26, n_slices=4, max_items=1, in_slots=2, out_slots=2, lib=lib)
     finally:
         os.environ.pop("VENC_ME", None)
     out = []
@@ -281,7 +281,7 @@ def _me_run(venc, frames, w, h, mode):
 
 
 @pytest.mark.parametrize("kind", ["synth", "flat", "white_noise", "static_noise", "stripes"])
-def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
+def test_successive_elimination_equals_exhaustive_search(venc, legacy_lib, orc, kind):
     """The pruned search (k_me) must return the same vectors and SADs as the exhaustive kernel
     (k_me_dense) and the oracle, including on content where the bound prunes nothing (flat,
     white noise: dense fallback) and where ties abound (flat, stripes: rank tie-break)."""
@@ -302,10 +302,10 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
         yy, xx = np.mgrid[0:h, 0:w]
         frames = [((((xx + 2 * t) // 4) % 2) * 200 + 20).astype(np.uint8) for t in range(n)]
         frames = [(f, np.full((h // 2, w // 2), 128, np.uint8), np.full((h // 2, w // 2), 128, np.uint8)) for f in frames]
-    a = _me_run(venc, frames, w, h, "pool")      # default: k_me_pool (persistent blocks, pooled survivors) + k_me_fix
-    d = _me_run(venc, frames, w, h, "tile")      # its predecessor k_me_tile
-    b = _me_run(venc, frames, w, h, "dense")     # exhaustive
-    c = _me_run(venc, frames, w, h, "plane")     # sums from the k_refsum plane, in-kernel dense fallback
+    a = _me_run(venc, frames, w, h, "pool")      # the product library: k_me_pool (pooled survivors) + k_me_fix
+    d = _me_run(venc, frames, w, h, "tile", legacy_lib)   # its predecessor k_me_tile (test-only library)
+    b = _me_run(venc, frames, w, h, "dense", legacy_lib)  # exhaustive
+    c = _me_run(venc, frames, w, h, "plane", legacy_lib)  # sums from the k_refsum plane, in-kernel dense fallback
     enc = orc.Encoder(w, h, qp=26, n_slices=4, keyint=100, threads=8)
     for t, (y, u, v) in enumerate(frames):
         enc.encode(y, u, v)
@@ -319,13 +319,13 @@ def test_successive_elimination_equals_exhaustive_search(venc, orc, kind):
             assert np.array_equal((a[t][0] >> 16).astype(np.uint16), enc.sad())
 
 
-def test_reference_block_sums_plane(venc):
+def test_reference_block_sums_plane(venc, legacy_lib):
     """k_refsum: P8(x,y) = S8(x,y) | S8(x+8,y) << 16 over the edge-replicated reconstruction."""
     w, h = 352, 288
     import os
     os.environ["VENC_ME"] = "plane"
     try:
-        eng = venc.Engine(w, h, qp=30, n_slices=2, max_items=1, in_slots=1, out_slots=1)
+        eng = venc.Engine(w, h, qp=30, n_slices=2, max_items=1, in_slots=1, out_slots=1, lib=legacy_lib)
     finally:
         os.environ.pop("VENC_ME", None)
     eng.upload(0, *venc.synth_frame(w, h, 0, 9))
@@ -343,7 +343,7 @@ def test_reference_block_sums_plane(venc):
     eng.close()
 
 
-def test_legacy_and_split_inter_kernels_agree(venc):
+def test_legacy_and_split_inter_kernels_agree(venc, legacy_lib):
     """k_inter_luma + k_inter_chroma (homogeneous waves) against the first k_inter."""
     import os
     w, h, n = 352, 288, 4
@@ -352,7 +352,7 @@ def test_legacy_and_split_inter_kernels_agree(venc):
     for mode in ("legacy", "split"):
         os.environ["VENC_INTER"] = mode
         try:
-            eng = venc.Engine(w, h, qp=24, n_slices=3, max_items=1, in_slots=2, out_slots=2)
+            eng = venc.Engine(w, h, qp=24, n_slices=3, max_items=1, in_slots=2, out_slots=2, lib=legacy_lib if mode == "legacy" else None)
         finally:
             os.environ.pop("VENC_INTER", None)
         res = []

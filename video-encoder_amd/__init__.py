@@ -123,10 +123,9 @@ def _load(path):
     return C.CDLL(path, mode=C.RTLD_GLOBAL)
 
 
-def hip_lib():
-    global _hip
-    if _hip is None:
-        L = _load(LIB_HIP)
+def bind_hip(L):
+    """ctypes signatures of include/venc_hip.h on a loaded library (the product library, or the test-only legacy build)."""
+    if True:
         L.venc_last_error.restype = C.c_char_p
         L.venc_open.argtypes = [C.POINTER(VencConfig), C.POINTER(C.c_void_p)]
         L.venc_close.argtypes = [C.c_void_p]
@@ -163,7 +162,13 @@ def hip_lib():
         L.venc_band_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
         L.venc_stream_handle.restype = C.c_void_p
         L.venc_stream_handle.argtypes = [C.c_void_p]
-        _hip = L
+    return L
+
+
+def hip_lib():
+    global _hip
+    if _hip is None:
+        _hip = bind_hip(_load(LIB_HIP))
     return _hip
 
 
@@ -308,8 +313,9 @@ def synth_frame(width, height, frame_index, seed=0x1234ABCD):
 class Engine:
     """One encoder context on one GPU: frame slots in, slice RBSPs out."""
 
-    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0):
-        self.L = hip_lib()
+    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None):
+        """lib: a library bound with bind_hip() instead of the product library (tests load the legacy build this way)."""
+        self.L = lib if lib is not None else hip_lib()
         self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device)
         h = C.c_void_p()
         rc = self.L.venc_open(C.byref(self.cfg), C.byref(h))
@@ -539,16 +545,24 @@ class X264Encoder:
     def encode_resident(self, dev_ptr, frame_stride, n_frames, sink=None, first_pts=0, repeats=1):
         """Encode frames already in HBM; sink(payload_bytes, nal_list, pts, keyframe) per frame, or count only.
         repeats > 1: that many passes of the clip as one stream (x264_venc_encode_resident_loop)."""
+        raised = []
+
         def _cb(user, nals, n, size, pic):
-            if sink is not None:
-                base = C.addressof(nals[0].p_payload.contents)
-                lst = [(nals[i].i_type, nals[i].i_ref_idc, C.addressof(nals[i].p_payload.contents) - base,
-                        nals[i].i_payload) for i in range(n)]
-                sink(C.string_at(base, size), lst, pic.contents.i_pts, bool(pic.contents.b_keyframe))
-            return 0
+            try:
+                if sink is not None:
+                    base = C.addressof(nals[0].p_payload.contents)
+                    lst = [(nals[i].i_type, nals[i].i_ref_idc, C.addressof(nals[i].p_payload.contents) - base,
+                            nals[i].i_payload) for i in range(n)]
+                    sink(C.string_at(base, size), lst, pic.contents.i_pts, bool(pic.contents.b_keyframe))
+                return 0
+            except BaseException as e:  # never unwind through the C frames: stop the loop, re-raise below
+                raised.append(e)
+                return -1
         cb = SINK_FN(_cb)
         r = self.L.x264_venc_encode_resident_loop(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, repeats, first_pts,
                                                   C.cast(cb, C.c_void_p), None)
+        if raised:
+            raise raised[0]
         if r < 0:
             raise self._error("x264_venc_encode_resident_loop failed: %s" % hip_lib().venc_last_error().decode())
         return r

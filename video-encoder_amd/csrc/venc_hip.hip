@@ -17,8 +17,10 @@
 
 #include "../../include/venc_hip.h"
 #include "venc_kernels.hip"
-#include "venc_me.hip"
 #include "venc_me2.hip"
+#ifdef VENC_LEGACY_KERNELS
+#include "venc_me.hip"
+#endif
 #include "venc_me3.hip"
 #include "venc_inter2.hip"
 #include "venc_cavlc_p.hip"
@@ -37,7 +39,8 @@ static thread_local char g_err[512] = "";
         }                                                                                     \
     } while (0)
 
-#define VENC_EVENTS 256
+#define VENC_EVENTS_MIN 256 /* completion tickets: one event per step; the ring holds max(this, out_slots + 2) of them, and a step
+                              occupies at least one output slot until its frames are delivered, so a live ticket is never recycled */
 /* Motion vectors, levels and macroblock records live in a ring of VENC_RING step slots: the entropy chain of step t
  * (second stream) reads slot t % RING while the main chain runs ahead.  Slot t % RING was last read by the entropy
  * chain of step t - RING, so the main stream has to wait for that chain only now and then: every VENC_RING_WAIT
@@ -52,11 +55,17 @@ struct venc_ctx {
     venc_bufs b;
     hipStream_t stream;  /* main chain: ingest, k_me, k_me_fix, k_inter / k_intra */
     hipStream_t stream2; /* entropy chain of the same step: k_cavlc, k_scan, k_pack -- overlaps the next step's main chain */
+    hipStream_t stream_copy; /* host -> HBM ingest (venc_upload): overlaps both kernel chains; the main chain waits for a slot's copy
+                                event only when a step reads that slot */
+    hipEvent_t *ev_copy;     /* [in_slots] copy of the slot's frame complete */
+    uint8_t *copy_pending;   /* [in_slots] ev_copy[slot] recorded and not yet waited for by the main chain */
+    int last_copy_slot;      /* slot of the most recent venc_upload (-1: none): what venc_upload_sync waits for */
     hipEvent_t ev_main[2];            /* per parity: main chain of the step done */
     hipEvent_t ev_side[VENC_RING];    /* per ring slot: k_cavlc of the step that used the slot done */
     long long side_step[VENC_RING];  /* step whose entropy chain recorded ev_side[slot] (-1: none) */
     int overlap;
-    hipEvent_t ev[VENC_EVENTS];
+    hipEvent_t *ev; /* [n_events] */
+    int n_events;
     int ev_done; /* newest ticket known to be complete (-1: none) */
     int ev_next;
     int parity;
@@ -140,8 +149,17 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
-    for (int i = 0; i < VENC_EVENTS; i++)
-        if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
+    if (c->ev)
+        for (int i = 0; i < c->n_events; i++)
+            if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    free(c->ev);
+    if (c->ev_copy)
+        for (int i = 0; i < c->cfg.in_slots; i++)
+            if (c->ev_copy[i]) (void)hipEventDestroy(c->ev_copy[i]);
+    free(c->ev_copy);
+    free(c->copy_pending);
+    if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
     for (int i = 0; i < 2; i++) {
         if (c->ev_main[i]) (void)hipEventDestroy(c->ev_main[i]);
     }
@@ -265,7 +283,19 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         } else
             OPEN_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     }
-    for (int i = 0; i < VENC_EVENTS; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    c->n_events = cfg->out_slots + 2 > VENC_EVENTS_MIN ? cfg->out_slots + 2 : VENC_EVENTS_MIN;
+    c->ev = (hipEvent_t *)calloc((size_t)c->n_events, sizeof(hipEvent_t));
+    c->ev_copy = (hipEvent_t *)calloc((size_t)(cfg->in_slots > 0 ? cfg->in_slots : 1), sizeof(hipEvent_t));
+    c->copy_pending = (uint8_t *)calloc((size_t)(cfg->in_slots > 0 ? cfg->in_slots : 1), 1);
+    c->last_copy_slot = -1;
+    if (!c->ev || !c->ev_copy || !c->copy_pending) {
+        SET_ERR("venc_open: out of host memory");
+        venc_close(c);
+        return -1;
+    }
+    for (int i = 0; i < c->n_events; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < cfg->in_slots; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_main[i], hipEventDisableTiming));
     }
@@ -299,6 +329,20 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         const char *e = getenv("VENC_INTRA");
         c->intra_legacy = e && !strcmp(e, "legacy");
     }
+#ifndef VENC_LEGACY_KERNELS
+    {
+        /* the first-generation kernels (VENC_ME=tile|plane|dense, VENC_INTER=legacy, VENC_INTRA=legacy) are on-GPU test
+         * oracles: they live in libvenc_hip_legacy.so (tests/conftest.py loads it), not in the product library */
+        const char *m = getenv("VENC_ME"), *i1 = getenv("VENC_INTER"), *i2 = getenv("VENC_INTRA");
+        if ((m && strcmp(m, "pool")) || (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) || (i1 && !strcmp(i1, "legacy")) ||
+            (i2 && !strcmp(i2, "legacy"))) {
+            SET_ERR("venc_open: the first-generation kernels selected by VENC_ME / VENC_INTER / VENC_INTRA are built into "
+                    "libvenc_hip_legacy.so (test-only), not into this library");
+            venc_close(c);
+            return -1;
+        }
+    }
+#endif
     c->intra_waves = (maxrows + 1) / 2 < INTRA_MAX_WAVES ? (maxrows + 1) / 2 : INTRA_MAX_WAVES; /* two MB rows per wave */
     c->max_slice_mbs = maxrows * g.mbw;
     OPEN_OK(hipMalloc(&c->d_slice_rows, sizeof(int) * (g.n_slices + 1)));
@@ -354,8 +398,10 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMemset(b.unit_count, 0, 2 * G * VENC_COUNTER_STRIDE * 4));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
     b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
+#ifdef VENC_LEGACY_KERNELS
     OPEN_OK(hipMalloc(&b.refsum, G * b.refsum_item * 4));
     OPEN_OK(hipMemset(b.refsum, 0, G * b.refsum_item * 4));
+#endif
     {
         const char *m = getenv("VENC_ME");
         c->me_mode = 0;
@@ -386,11 +432,18 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
 
     /* pinned, device-mapped output pool: header | slice table | data */
     b.out_data_off = (uint32_t)((sizeof(venc_out_header) + (size_t)g.n_slices * sizeof(venc_slice_out) + 63) & ~(size_t)63);
-    /* capacity per frame: generous for the QP range; overflow is reported, never silent */
-    b.out_cap = (uint32_t)((size_t)g.cw * g.ch * (cfg->qp < 20 ? 6 : cfg->qp < 30 ? 3 : 2) / 4 + 65536);
+    /* Capacity per frame.  H.264 Annex A.3.1 caps macroblock_layer() at 3200 bits = 400 bytes per macroblock for the
+     * Baseline family; a macroblock above that is not a conforming stream whatever the buffer holds (libx264 re-codes it as
+     * I_PCM, a mode this subset does not have).  QP < 40 gets exactly that bound = 1.56 bytes per pixel.  Uniform white
+     * noise, the densest content there is, measures with the oracle (352x288, bytes per pixel, largest macroblock in bits):
+     * QP 12: 1.89 / 4179, 16: 1.65 / 3615, 20: 1.40 / 3086, 26: 1.09 / 2389, 30: 0.93 / 2008, 40: 0.58 / 1296, 51: 0.23 / 545
+     * -- so from QP ~19 up every content fits, below it noise leaves the conformance limit and the slot with it.  QP >= 40:
+     * 256 bytes per macroblock (twice what noise needs there).  + slice headers and the per-slice 4-byte alignment.
+     * Overflow is reported through header.error -> venc_get_frame() = -3, never silent. */
+    b.out_cap = (uint32_t)((size_t)g.nmb * (cfg->qp < 40 ? 400 : 256) + (size_t)g.n_slices * 64 + 4096);
     b.out_slot_bytes = ((size_t)b.out_data_off + b.out_cap + 255) & ~(size_t)255;
     OPEN_OK(hipHostMalloc((void **)&c->h_out, b.out_slot_bytes * cfg->out_slots, hipHostMallocMapped));
-    memset(c->h_out, 0, b.out_slot_bytes * cfg->out_slots);
+    for (int i = 0; i < cfg->out_slots; i++) memset(c->h_out + (size_t)i * b.out_slot_bytes, 0, b.out_data_off); /* header + slice table */
     void *dview = NULL;
     OPEN_OK(hipHostGetDevicePointer(&dview, c->h_out, 0));
     b.out_base = (uint8_t *)dview;
@@ -463,15 +516,28 @@ extern "C" int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int sy, cons
     HIP_OK(hipSetDevice(c->cfg.device));
     const int w = c->g.w, h = c->g.h;
     uint8_t *d = c->d_in + (size_t)slot * c->b.in_frame_stride;
-    HIP_OK(hipMemcpy2DAsync(d, (size_t)w, y, (size_t)sy, (size_t)w, (size_t)h, hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpy2DAsync(d + (size_t)w * h, (size_t)(w / 2), u, (size_t)su, (size_t)(w / 2), (size_t)(h / 2),
-                            hipMemcpyHostToDevice, c->stream));
-    HIP_OK(hipMemcpy2DAsync(d + (size_t)w * h * 5 / 4, (size_t)(w / 2), v, (size_t)sv, (size_t)(w / 2), (size_t)(h / 2),
-                            hipMemcpyHostToDevice, c->stream));
+    /* Ingest runs on its own stream: the copy of frame f + 1 overlaps the kernels of frame f (and earlier), and the caller
+     * that must get its picture back (venc_upload_sync) waits for the copy alone, not for the kernel chain.  The pool slot is
+     * free to overwrite: the caller reuses a slot only after the frame that last used it was delivered (its step complete).
+     * Tight planes in one pinned allocation (what x264_picture_alloc hands out) go as ONE copy. */
+    hipStream_t sc = c->stream_copy;
+    const size_t ysz = (size_t)w * h;
+    if (sy == w && su == w / 2 && sv == w / 2 && u == y + ysz && v == u + ysz / 4) {
+        HIP_OK(hipMemcpyAsync(d, y, ysz * 3 / 2, hipMemcpyHostToDevice, sc));
+    } else {
+        HIP_OK(hipMemcpy2DAsync(d, (size_t)w, y, (size_t)sy, (size_t)w, (size_t)h, hipMemcpyHostToDevice, sc));
+        HIP_OK(hipMemcpy2DAsync(d + ysz, (size_t)(w / 2), u, (size_t)su, (size_t)(w / 2), (size_t)(h / 2), hipMemcpyHostToDevice, sc));
+        HIP_OK(hipMemcpy2DAsync(d + ysz * 5 / 4, (size_t)(w / 2), v, (size_t)sv, (size_t)(w / 2), (size_t)(h / 2), hipMemcpyHostToDevice, sc));
+    }
+    HIP_OK(hipEventRecord(c->ev_copy[slot], sc));
+    c->copy_pending[slot] = 1;
+    c->last_copy_slot = slot;
     return 0;
 }
+/* the source planes of every venc_upload so far may be reused (waits for the copies only, never for kernels) */
 extern "C" int venc_upload_sync(venc_ctx *c) {
-    HIP_OK(hipStreamSynchronize(c->stream));
+    if (c->last_copy_slot < 0) return 0;
+    HIP_OK(hipEventSynchronize(c->ev_copy[c->last_copy_slot])); /* one stream: the last copy covers the earlier ones */
     return 0;
 }
 
@@ -507,6 +573,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         }
         S.in_slot[i] = in_slots[i];
         S.out_slot[i] = out_slots[i];
+        if (c->d_in && c->b.in_base == c->d_in && c->copy_pending[in_slots[i]]) { /* the frame's ingest copy precedes the step */
+            HIP_OK(hipStreamWaitEvent(c->stream, c->ev_copy[in_slots[i]], 0));
+            c->copy_pending[in_slots[i]] = 0;
+        }
         S.idr_id[i] = idr_ids ? idr_ids[i] : 0;
     }
     const venc_geom &g = c->g;
@@ -529,9 +599,12 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     }
     if (is_idr) {
         prof_begin(c, KID_INTRA, s1);
+#ifdef VENC_LEGACY_KERNELS
         if (c->intra_legacy)
             hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
-        else {
+        else
+#endif
+        {
             /* transform off the dependency chain, DC chain, reconstruction (venc_intra2.hip) */
             hipLaunchKernelGGL(k_intra_fwd, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
             hipLaunchKernelGGL(k_intra_dc, dim3(band_slices, 1, n_items), dim3(1024), 0, s1, g, b, S, c->intra_cw);
@@ -543,6 +616,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
          * transform kernel does not do that and takes a memset node instead */
         if (c->inter_legacy) HIP_OK(hipMemsetAsync(b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
+#ifdef VENC_LEGACY_KERNELS
         if (c->me_mode == 2)
             hipLaunchKernelGGL(k_me_dense, dim3((g.mbw + ME_TILE - 1) / ME_TILE, band_rows, n_items), dim3(256), 0, s1, g, b, S);
         else if (c->me_mode == 1)
@@ -551,6 +625,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_me_tile, dim3((g.mbw + T2_MBX - 1) / T2_MBX, (band_rows + T2_MBY - 1) / T2_MBY, n_items), dim3(512), 0,
                                s1, g, b, S);
         else
+#endif
         {
             const int ntx = (g.mbw + T2_MBX - 1) / T2_MBX, nty = (band_rows + T2_MBY - 1) / T2_MBY;
             /* raster order, or (VENC_ME_XCD=1) runs of 64 tiles dealt to the XCDs in rotation: grid.x is then the picture's
@@ -567,11 +642,14 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
         }
+#ifdef VENC_LEGACY_KERNELS
         if (c->inter_legacy) {
             prof_begin(c, KID_INTER, s1);
             hipLaunchKernelGGL(k_inter, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
-        } else {
+        } else
+#endif
+        {
             /* luma transform and chroma transform: independent blocks of one launch */
             const int n_luma = (band_mbs + 15) / 16, n_chroma = (band_mbs + 31) / 32;
             prof_begin(c, KID_INTER, s1);
@@ -579,12 +657,14 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             prof_end(c, s1);
         }
     }
+#ifdef VENC_LEGACY_KERNELS
     if (c->me_mode == 1) { /* block sums of the frame just reconstructed = reference of the next P step */
         prof_begin(c, KID_REFSUM, s1);
         hipLaunchKernelGGL(k_refsum, dim3((g.cw + 17 + RS_TW - 1) / RS_TW, (g.ch + 25 + RS_TH - 1) / RS_TH, n_items), dim3(256), 0,
                            s1, g, b, S);
         prof_end(c, s1);
     }
+#endif
     if (c->overlap) {
         HIP_OK(hipEventRecord(c->ev_main[p], s1));
         HIP_OK(hipStreamWaitEvent(s2, c->ev_main[p], 0));
@@ -713,23 +793,24 @@ extern "C" void *venc_stream_handle(venc_ctx *c) { return (void *)c->stream; }
 
 extern "C" int venc_mark(venc_ctx *c) {
     const int t = c->ev_next;
-    HIP_OK(hipEventRecord(c->ev[t % VENC_EVENTS], c->overlap ? c->stream2 : c->stream));
+    HIP_OK(hipEventRecord(c->ev[t % c->n_events], c->overlap ? c->stream2 : c->stream));
     c->ev_next++;
     return t;
 }
 extern "C" int venc_wait(venc_ctx *c, int ticket) {
-    if (ticket < 0 || ticket >= c->ev_next || c->ev_next - ticket > VENC_EVENTS) {
+    if (ticket < 0 || ticket >= c->ev_next || c->ev_next - ticket > c->n_events) {
         SET_ERR("venc_wait: stale ticket %d", ticket);
         return -1;
     }
     /* tickets complete in order (one stream records them): the frames of a step share a ticket, and a later ticket
      * that has been waited for covers the earlier ones -- no second trip into the runtime for them */
     if (ticket <= c->ev_done) return 0;
-    HIP_OK(hipEventSynchronize(c->ev[ticket % VENC_EVENTS]));
+    HIP_OK(hipEventSynchronize(c->ev[ticket % c->n_events]));
     c->ev_done = ticket;
     return 0;
 }
 extern "C" int venc_sync(venc_ctx *c) {
+    HIP_OK(hipStreamSynchronize(c->stream_copy));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     return 0;
@@ -793,7 +874,13 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         case 10: src = c->b.me_flag + item * nmb, n = nmb; break;
         case 12: src = c->b.intra_d0 + item * nmb * 32, n = nmb * 32 * 4; break;
         case 13: src = c->b.intra_rec + item * nmb * INTRA_REC_DWORDS, n = nmb * INTRA_REC_DWORDS * 4; break;
-        case 8: src = c->b.refsum + item * c->b.refsum_item, n = c->b.refsum_item * 4; break;
+        case 8:
+            if (!c->b.refsum) {
+                SET_ERR("venc_debug_read: the block-sums plane exists in the legacy test library only");
+                return -1;
+            }
+            src = c->b.refsum + item * c->b.refsum_item, n = c->b.refsum_item * 4;
+            break;
         default: SET_ERR("venc_debug_read: unknown selector %d", what); return -1;
     }
     if (dst_bytes < n) {

@@ -111,6 +111,7 @@ DEVFN uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
+#ifdef VENC_LEGACY_KERNELS /* first-generation kernels: built into libvenc_hip_legacy.so only (on-GPU test oracles), not into the product library */
 /* ================================================================== k_me
  * One block = 8 horizontally adjacent macroblocks of one MB row; one half-wave
  * (32 lanes) per macroblock.  Lane l of a half-wave owns displacement column
@@ -497,6 +498,8 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
     }
 }
 
+#endif /* VENC_LEGACY_KERNELS */
+
 /* ================================================================== k_intra
  * Intra16x16 with DC prediction needs the reconstructed left and top
  * neighbours, so a slice is a 2-D dependency wavefront.  One block per slice;
@@ -520,6 +523,7 @@ DEVFN void load_cur_rows(const uint8_t *cur, int cstride, int pw, int ph, int px
     }
 }
 
+#ifdef VENC_LEGACY_KERNELS
 __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ int s_bot[2 * INTRA_MAX_WAVES][4][5];
     const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
@@ -650,6 +654,8 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
         __syncthreads(); /* the next pass re-reads this pass's last reconstructed row from memory */
     }
 }
+
+#endif /* VENC_LEGACY_KERNELS */
 
 /* ================================================================== k_cavlc
  * Half-wave per macroblock, one lane per syntax element group, in syntax order:

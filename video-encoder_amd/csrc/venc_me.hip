@@ -110,7 +110,6 @@ __global__ __launch_bounds__(256) void k_refsum(venc_geom g, venc_bufs B, venc_s
 }
 
 #define SEA_PW (ME_TILE * 16 + 20) /* packed-sum window row: 145 dwords used, padded to 16-byte multiples */
-#define SEA_LIST 64               /* survivors evaluated one by one; more -> dense fallback */
 
 /* SAD of the macroblock against the reference block at window position (cx, cy), computed by
  * the 32 lanes of a half-wave (8 pixels each); the result is identical in all 32 lanes. */

@@ -18,6 +18,7 @@
  * redone by k_me_fix with the exhaustive half-wave search.
  */
 
+#define SEA_LIST 64 /* survivors a macroblock may keep; more: exhaustive search by k_me_fix */
 #define T2_MBX 8
 #define T2_MBY 2
 #define T2_WR (T2_MBY * 16 + 32) /* window rows: 64 */
@@ -45,6 +46,7 @@
 DEVFN uint2 pk4_add(uint2 a, uint2 b) { return make_uint2(a.x + b.x, a.y + b.y); }
 DEVFN uint2 pk4_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y); }
 
+#ifdef VENC_LEGACY_KERNELS /* k_me_tile, the predecessor of k_me_pool: test-only library */
 /* SAD of one macroblock at window position (col0 + cx, row0 + cy), 8 pixels per lane of a half-wave */
 DEVFN uint32_t me2_coop_sad(const uint32_t *s_win, int col0, int row0, int lane, uint32_t c0, uint32_t c1, int cx, int cy) {
     const int l32 = lane & 31;
@@ -290,6 +292,8 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
         B.me_cnt[mbidx] = (uint8_t)min(cnt, 255u); /* survivors of the bound test (introspection) */
     }
 }
+
+#endif /* VENC_LEGACY_KERNELS */
 
 /* Exhaustive redo of the macroblocks k_me_tile flagged (bound not selective enough), one
  * macroblock per block so that the few flagged ones (around occlusions; ~0.5 % on the synthetic

@@ -392,7 +392,8 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         if (venc_upload(h->ctx, (int)(f % h->pool), pic_in->img.plane[0], pic_in->img.i_stride[0], pic_in->img.plane[1],
                         pic_in->img.i_stride[1], pic_in->img.plane[2], pic_in->img.i_stride[2]) != 0)
             return -1;
-        /* the caller rewrites pic_in right after this call (av_encode.c:545) */
+        /* the caller rewrites pic_in right after this call (av_encode.c:545): wait for the ingest copy -- on its own stream,
+         * so this does not wait for the kernels of earlier frames, which keep running beside the copy of the next frame */
         if (venc_upload_sync(h->ctx) != 0) return -1;
         h->n_in++;
         if (launch_pending(h, 0) != 0) return -1;
@@ -409,14 +410,26 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
     return x264_venc_encode_resident_loop(h, d_frames, frame_stride, n_frames, 1, first_pts, sink, user);
 }
 
+static int resident_loop(x264_t *h, int n_frames, int64_t first_pts, x264_venc_sink sink, void *user);
+
 int x264_venc_encode_resident_loop(x264_t *h, const void *d_frames, uint64_t frame_stride, int clip_frames, int repeats,
                                    int64_t first_pts, x264_venc_sink sink, void *user) {
     if (!h || !d_frames || clip_frames < 1 || repeats < 1 || h->n_in != h->n_out) return -1;
     if ((int64_t)clip_frames * repeats > 0x7fffffff) return -1;
     if (venc_set_input(h->ctx, d_frames, (size_t)frame_stride, clip_frames) != 0) return -1;
-    const int n_frames = clip_frames * repeats;
     h->external_input = 1;
     h->ext_clip = clip_frames;
+    const int r = resident_loop(h, clip_frames * repeats, first_pts, sink, user);
+    h->external_input = 0; /* on every path: after an error the encoder takes host pictures again */
+    if (r < 0) {
+        /* frames still inside belong to the failed call: drop them, so that n_in == n_out holds for the next call */
+        (void)venc_sync(h->ctx);
+        h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
+    }
+    return r;
+}
+
+static int resident_loop(x264_t *h, int n_frames, int64_t first_pts, x264_venc_sink sink, void *user) {
     /* frame numbering restarts so that resident frame f is input slot f */
     h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
     int delivered = 0, f = 0;
@@ -460,7 +473,6 @@ int x264_venc_encode_resident_loop(x264_t *h, const void *d_frames, uint64_t fra
     if (trace)
         fprintf(stderr, "venc trace: %d frames, total %.3f ms = launch %.3f + package(wait+escape) %.3f + sink %.3f\n", delivered,
                 now_ms() - t0, t_launch, t_asm, t_sink);
-    h->external_input = 0;
     return delivered;
 }
 
