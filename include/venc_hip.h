@@ -14,10 +14,10 @@
  *   - up to max_items independent prediction chains ("items": streams or closed
  *     GOPs) that advance in lock-step, one frame per step;
  *   - an output pool in pinned host memory that the pack kernel writes directly.
- * One venc_encode_step() launches, on the context's HIP stream,
- *   P step: k_me -> k_inter -> k_cavlc -> k_scan -> k_pack
- *   I step: k_intra      -> k_cavlc -> k_scan -> k_pack
- * for all items at once (grid z = item).  Nothing blocks until venc_wait().
+ * One venc_encode_step() launches, for all items at once (grid z = item),
+ *   main chain (stream 1)     P: k_me_pool -> k_me_fix -> k_inter_fused    I: k_intra_fwd -> k_intra_dc -> k_intra_rec
+ *   entropy chain (stream 2)  P: k_skip -> k_cavlc_p -> k_scan -> k_pack    I: k_cavlc -> k_scan -> k_pack
+ * the entropy chain possibly deferred and launched once for several P steps.  Nothing blocks until venc_wait().
  *
  * All functions return 0 on success, a negative value on error (never abort,
  * never print unless VENC_DEBUG is set) -- the reference's convention for the
@@ -123,10 +123,14 @@ int venc_band_import(venc_ctx *c, int n_items, const void *d_chunk, size_t item_
                      int halo_rows);
 void *venc_stream_handle(venc_ctx *c); /* hipStream_t of the main kernel chain */
 
-/* Completion tracking: venc_mark() records an event after everything enqueued
- * so far; venc_wait(ticket) blocks the host until that point. */
+/* Completion tracking: venc_mark() returns a ticket for everything issued so
+ * far; venc_wait(ticket) blocks the host until that point.  The engine may defer
+ * the entropy chain of up to four consecutive P steps and launch it once for all
+ * of them (one launch covers 4 x max_items pictures); venc_wait on a ticket of a
+ * deferred step launches it first, venc_flush() does so without waiting. */
 int venc_mark(venc_ctx *c);
 int venc_wait(venc_ctx *c, int ticket);
+int venc_flush(venc_ctx *c);
 int venc_sync(venc_ctx *c);
 /* 1 (default): the entropy kernels of a step (k_cavlc, k_scan, k_pack) run on a second HIP
  * stream beside the next step's motion/transform kernels; 0: one stream, no concurrency. */

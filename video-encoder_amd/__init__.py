@@ -129,7 +129,7 @@ def bind_hip(L):
         L.venc_last_error.restype = C.c_char_p
         L.venc_open.argtypes = [C.POINTER(VencConfig), C.POINTER(C.c_void_p)]
         L.venc_close.argtypes = [C.c_void_p]
-        for n in ("venc_mb_width", "venc_mb_height", "venc_n_slices", "venc_upload_sync", "venc_mark", "venc_sync"):
+        for n in ("venc_mb_width", "venc_mb_height", "venc_n_slices", "venc_upload_sync", "venc_mark", "venc_sync", "venc_flush"):
             getattr(L, n).argtypes = [C.c_void_p]
         L.venc_frame_bytes.restype = C.c_size_t
         L.venc_frame_bytes.argtypes = [C.c_void_p]

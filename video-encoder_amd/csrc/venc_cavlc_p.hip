@@ -99,8 +99,9 @@ __global__ __launch_bounds__(CAVLC_P_MAX_THREADS) void k_cavlc_p(venc_geom g, ve
     const uint32_t nthreads = blockDim.x;
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
     const int item = blockIdx.z, tid = threadIdx.x;
-    /* the other unit counter: read last by the previous P step's k_cavlc_p, filled next by the next one's k_skip */
-    if (blockIdx.x == 0 && tid == 0) B.unit_count_next[item * VENC_COUNTER_STRIDE] = 0;
+    /* the other set of unit counters: read last by the previous P batch's k_cavlc_p, filled next by the next one's k_skip
+     * (which may cover more (step, item) pairs than this launch: all of them are cleared) */
+    if (blockIdx.x == 0 && item == 0 && tid < B.vcap) B.unit_count_next[tid * VENC_COUNTER_STRIDE] = 0;
     const uint32_t count = B.unit_count[item * VENC_COUNTER_STRIDE];
     const uint32_t *list = B.unit_list + (size_t)item * g.nmb * 7;
     if (blockIdx.x * nthreads >= count) return; /* whole block: nothing listed for it */

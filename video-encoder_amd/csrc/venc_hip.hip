@@ -17,12 +17,12 @@
 
 #include "../../include/venc_hip.h"
 #include "venc_kernels.hip"
+#include "venc_inter2.hip"
 #include "venc_me2.hip"
 #ifdef VENC_LEGACY_KERNELS
 #include "venc_me.hip"
 #endif
 #include "venc_me3.hip"
-#include "venc_inter2.hip"
 #include "venc_cavlc_p.hip"
 #include "venc_intra2.hip"
 #include "venc_synth.h"
@@ -47,7 +47,15 @@ static thread_local char g_err[512] = "";
  * steps it waits for the entropy chain of step t + WAIT - 1 - RING, which covers the next WAIT steps.  (With two
  * slots the wait came every step and cost the main stream ~5 us each time -- 3 % of a 1080p step.) */
 #define VENC_RING 8
-#define VENC_RING_WAIT 6
+#define VENC_RING_WAIT 4
+/* ENTROPY BATCH.  Nothing on the GPU waits for a step's bitstream, so the entropy chain need not run once per step: the
+ * launcher collects up to VENC_EBATCH consecutive P steps (ring slots of one aligned group of four, same item count) and
+ * launches k_skip / k_cavlc_p / k_scan / k_pack ONCE for all of them, with the grid's item index running over (step, item)
+ * pairs.  The chain's kernels are latency bound (a listed unit is one lane's serial bit emission; k_scan and k_pack are
+ * dependent round trips): four steps per launch cost little more than one, and the chain stops being co-critical with the
+ * main chain (round 1: 3.8 ms against 4.2 ms per 1080p pass).  A wait for a ticket of a step whose batch is still open
+ * flushes the batch first, so streaming callers (one frame per call) see batches of one. */
+#define VENC_EBATCH 4
 
 struct venc_ctx {
     venc_config cfg;
@@ -60,9 +68,24 @@ struct venc_ctx {
     hipEvent_t *ev_copy;     /* [in_slots] copy of the slot's frame complete */
     uint8_t *copy_pending;   /* [in_slots] ev_copy[slot] recorded and not yet waited for by the main chain */
     int last_copy_slot;      /* slot of the most recent venc_upload (-1: none): what venc_upload_sync waits for */
-    hipEvent_t ev_main[2];            /* per parity: main chain of the step done */
-    hipEvent_t ev_side[VENC_RING];    /* per ring slot: k_cavlc of the step that used the slot done */
-    long long side_step[VENC_RING];  /* step whose entropy chain recorded ev_side[slot] (-1: none) */
+    hipEvent_t ev_main[2];            /* alternating: main chains of an entropy batch done */
+    int ev_main_next;
+    hipEvent_t ev_luma[2];            /* alternating: search + luma transform of a P step done (the chroma launch on stream 2 waits) */
+    int ev_luma_next;
+    hipEvent_t ev_chroma;             /* the last chroma launch on stream 2 */
+    int chroma_pending;               /* ev_chroma recorded and not yet waited for by the main stream */
+    int fuse_luma;                    /* 1 (default): luma transform inside k_me_pool / k_me_fix, chroma on stream 2; VENC_FUSE=0: k_inter_fused on the main chain */
+    int fix_phase;                    /* which set of fix counters the next P step fills */
+    hipEvent_t ev_side[VENC_RING];    /* per ring slot: the entropy kernels that read the slot's motion vectors, levels and records are done */
+    long long side_step[VENC_RING];  /* step whose entropy batch recorded ev_side[slot] (-1: none) */
+    /* the open entropy batch: steps whose main chain is enqueued and whose entropy chain is not */
+    int eb_max;                       /* steps per batch: min(VENC_EBATCH, VENC_MAX_ITEMS / max_items), env VENC_ENTROPY_BATCH */
+    int eb_n;                         /* steps collected */
+    int eb_first_slot;                /* ring slot of the first */
+    long long eb_first_step;
+    venc_step eb_S;                   /* per (step, item) fields of the batch */
+    int eb_tickets[VENC_EBATCH * 2];  /* venc_mark() tickets issued while the batch was open: recorded at the flush */
+    int eb_nt;
     int overlap;
     hipEvent_t *ev; /* [n_events] */
     int n_events;
@@ -78,7 +101,7 @@ struct venc_ctx {
     uint8_t *d_row_slice;
     uint16_t *d_rank, *d_cand;
     int intra_waves;
-    int unit_phase;   /* which of the two unit counters the next P step fills */
+    int unit_phase;   /* which of the two sets of unit counters the next P batch fills */
     int me_xcd;       /* VENC_ME_XCD=1: XCD-aware tile order in k_me_pool (less fabric traffic, slightly slower) */
     int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
     int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
@@ -136,6 +159,15 @@ static void fill_qparams(venc_qparams *q, int qp) {
     q->f_inter = (1 << q->qbits) / 6;
 }
 
+static int entropy_flush(venc_ctx *c);
+/* the chroma transform of the last P step runs on the second stream: anything on the main stream that touches chroma
+ * reconstructions (intra pictures, band export / import) waits for it */
+static hipError_t main_waits_for_chroma(venc_ctx *c) {
+    if (!c->chroma_pending) return hipSuccess;
+    c->chroma_pending = 0;
+    return hipStreamWaitEvent(c->stream, c->ev_chroma, 0);
+}
+
 extern "C" int venc_abi_version(void) { return VENC_ABI_VERSION; }
 extern "C" const char *venc_last_error(void) { return g_err; }
 extern "C" int venc_device_count(void) {
@@ -147,6 +179,7 @@ extern "C" int venc_device_count(void) {
 extern "C" void venc_close(venc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
+    if (c->stream && c->stream2 && c->b.mbbits) (void)entropy_flush(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
@@ -162,7 +195,9 @@ extern "C" void venc_close(venc_ctx *c) {
     if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
     for (int i = 0; i < 2; i++) {
         if (c->ev_main[i]) (void)hipEventDestroy(c->ev_main[i]);
+        if (c->ev_luma[i]) (void)hipEventDestroy(c->ev_luma[i]);
     }
+    if (c->ev_chroma) (void)hipEventDestroy(c->ev_chroma);
     for (int i = 0; i < VENC_RING; i++)
         if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -298,7 +333,10 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     for (int i = 0; i < cfg->in_slots; i++) OPEN_OK(hipEventCreateWithFlags(&c->ev_copy[i], hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_main[i], hipEventDisableTiming));
+        OPEN_OK(hipEventCreateWithFlags(&c->ev_luma[i], hipEventDisableTiming));
     }
+    OPEN_OK(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
+    c->fuse_luma = !(getenv("VENC_FUSE") && atoi(getenv("VENC_FUSE")) == 0);
     for (int i = 0; i < VENC_RING; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
         c->side_step[i] = -1;
@@ -373,6 +411,17 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     venc_bufs &b = c->b;
     const size_t G = (size_t)cfg->max_items, nmb = (size_t)g.nmb;
     b.max_items = cfg->max_items;
+    {
+        /* steps per entropy batch: a power of two that divides the ring, (step, item) pairs within VENC_MAX_ITEMS */
+        const char *e = getenv("VENC_ENTROPY_BATCH");
+        int want = e ? atoi(e) : VENC_EBATCH;
+        if (want < 1) want = 1;
+        if (want > VENC_EBATCH) want = VENC_EBATCH;
+        c->eb_max = 1;
+        while (c->eb_max * 2 <= want && c->eb_max * 2 * cfg->max_items <= VENC_MAX_ITEMS) c->eb_max *= 2;
+        b.vcap = c->eb_max * cfg->max_items;
+    }
+    const size_t GV = (size_t)b.vcap; /* the entropy chain's own buffers hold a whole batch */
     b.in_frame_stride = (size_t)g.w * g.h * 3 / 2;
     /* the internal input pool is allocated on first use (venc_upload / venc_input_slot_ptr):
      * resident-input users (venc_set_input) never pay for it */
@@ -385,17 +434,17 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.levels, VENC_RING * G * nmb * VENC_MB_COEFS * 2));
     OPEN_OK(hipMalloc(&b.mbinfo, VENC_RING * G * nmb * sizeof(venc_mbinfo)));
     OPEN_OK(hipMemset(b.mbinfo, 0, VENC_RING * G * nmb * sizeof(venc_mbinfo)));
-    OPEN_OK(hipMalloc(&b.mbbits, G * nmb * VENC_MB_WORDS * 4));
-    OPEN_OK(hipMalloc(&b.mbnbits, G * nmb * 4));
-    OPEN_OK(hipMalloc(&b.ubits, G * nmb * 8 * 2));
-    OPEN_OK(hipMalloc(&b.mboff, G * nmb * 4));
-    OPEN_OK(hipMalloc(&b.codedmask, G * ((nmb + 63) / 64) * 8));
-    OPEN_OK(hipMalloc(&b.unit_list, G * nmb * 7 * 4));
-    OPEN_OK(hipMalloc(&b.slice_bits, G * VENC_MAX_SLICES * 4));
-    OPEN_OK(hipMalloc(&b.scan_done, G * VENC_COUNTER_STRIDE * 4));
-    OPEN_OK(hipMemset(b.scan_done, 0, G * VENC_COUNTER_STRIDE * 4));
-    OPEN_OK(hipMalloc(&b.unit_count, 2 * G * VENC_COUNTER_STRIDE * 4));
-    OPEN_OK(hipMemset(b.unit_count, 0, 2 * G * VENC_COUNTER_STRIDE * 4));
+    OPEN_OK(hipMalloc(&b.mbbits, GV * nmb * VENC_MB_WORDS * 4));
+    OPEN_OK(hipMalloc(&b.mbnbits, GV * nmb * 4));
+    OPEN_OK(hipMalloc(&b.ubits, GV * nmb * 8 * 2));
+    OPEN_OK(hipMalloc(&b.mboff, GV * nmb * 4));
+    OPEN_OK(hipMalloc(&b.codedmask, GV * ((nmb + 63) / 64) * 8));
+    OPEN_OK(hipMalloc(&b.unit_list, GV * nmb * 7 * 4));
+    OPEN_OK(hipMalloc(&b.slice_bits, GV * VENC_MAX_SLICES * 4));
+    OPEN_OK(hipMalloc(&b.scan_done, GV * VENC_COUNTER_STRIDE * 4));
+    OPEN_OK(hipMemset(b.scan_done, 0, GV * VENC_COUNTER_STRIDE * 4));
+    OPEN_OK(hipMalloc(&b.unit_count, 2 * GV * VENC_COUNTER_STRIDE * 4));
+    OPEN_OK(hipMemset(b.unit_count, 0, 2 * GV * VENC_COUNTER_STRIDE * 4));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
     b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
 #ifdef VENC_LEGACY_KERNELS
@@ -415,16 +464,16 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
-    OPEN_OK(hipMalloc(&b.fix_count, G * 4));
+    OPEN_OK(hipMalloc(&b.fix_count, 2 * G * 4));
     OPEN_OK(hipMalloc(&b.intra_rec, G * nmb * INTRA_REC_DWORDS * 4));
     OPEN_OK(hipMalloc(&b.intra_d0, G * nmb * 32 * 4));
-    OPEN_OK(hipMemset(b.fix_count, 0, G * 4));
+    OPEN_OK(hipMemset(b.fix_count, 0, 2 * G * 4));
     OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMalloc(&b.me_cnt, G * nmb));
     OPEN_OK(hipMemset(b.me_cnt, 0, G * nmb));
-    OPEN_OK(hipMalloc(&c->d_slice, G * g.n_slices * sizeof(venc_slice_out)));
+    OPEN_OK(hipMalloc(&c->d_slice, GV * g.n_slices * sizeof(venc_slice_out)));
     b.slice_first_row = c->d_slice_rows;
     b.row_slice = c->d_row_slice;
     b.me_rank = c->d_rank;
@@ -588,16 +637,20 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     b.mvsad_prev = c->b.mvsad + (size_t)rs_prev * GN;
     b.levels = c->b.levels + (size_t)rs * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
-    b.unit_count = c->b.unit_count + (size_t)c->unit_phase * c->b.max_items * VENC_COUNTER_STRIDE;
-    b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.max_items * VENC_COUNTER_STRIDE;
-    if (!is_idr) c->unit_phase ^= 1;
-    hipStream_t s1 = c->stream, s2 = c->overlap ? c->stream2 : c->stream;
+    hipStream_t s1 = c->stream;
+    /* an open entropy batch takes this step only if it continues it: same kind of picture (P), same items, same band,
+     * the next ring slot of the same aligned group */
+    if (c->eb_n > 0 && !(!is_idr && !c->eb_S.is_idr && n_items == c->cfg.max_items && c->eb_S.slice0 == S.slice0 && c->eb_S.slice1 == S.slice1 &&
+                         rs == c->eb_first_slot + c->eb_n && rs / c->eb_max == c->eb_first_slot / c->eb_max && c->eb_n < c->eb_max))
+        if (entropy_flush(c) != 0) return -1;
     if (c->overlap && c->step_no % VENC_RING_WAIT == 0) {
-        /* the entropy chain of step_no + WAIT - 1 - RING has released every slot the next WAIT steps overwrite */
+        /* the next WAIT steps overwrite the ring slots of steps step_no - RING .. step_no - RING + WAIT - 1: the entropy
+         * batch that read the last of them has been launched (batches never span a group of WAIT slots) and covers the others */
         const long long need = c->step_no + VENC_RING_WAIT - 1 - VENC_RING;
         if (need >= 0 && c->side_step[need % VENC_RING] == need) HIP_OK(hipStreamWaitEvent(s1, c->ev_side[need % VENC_RING], 0));
     }
     if (is_idr) {
+        HIP_OK(main_waits_for_chroma(c)); /* the intra kernels overwrite chroma planes the last P step's chroma launch may still read */
         prof_begin(c, KID_INTRA, s1);
 #ifdef VENC_LEGACY_KERNELS
         if (c->intra_legacy)
@@ -612,9 +665,13 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         }
         prof_end(c, s1);
     } else {
-        /* fix_count is zero here: zeroed at open and by k_inter_fused once k_me_fix has consumed it; the legacy
-         * transform kernel does not do that and takes a memset node instead */
-        if (c->inter_legacy) HIP_OK(hipMemsetAsync(b.fix_count, 0, (size_t)c->b.max_items * 4, s1));
+        /* Two sets of fix counters alternate between P steps: this step's search fills one and zeroes the other (the
+         * legacy searches do not: a memset node instead). */
+        b.fix_count = c->b.fix_count + (size_t)c->fix_phase * c->b.max_items;
+        b.fix_count_next = c->b.fix_count + (size_t)(c->fix_phase ^ 1) * c->b.max_items;
+        c->fix_phase ^= 1;
+        const bool fuse = c->fuse_luma && c->me_mode == 0 && !c->inter_legacy;
+        if (c->me_mode != 0) HIP_OK(hipMemsetAsync(b.fix_count_next, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
 #ifdef VENC_LEGACY_KERNELS
         if (c->me_mode == 2)
@@ -633,13 +690,13 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             const int runs = (ntx * nty + 63) / 64;
             const uint32_t tx_magic = ntx > 1 ? (uint32_t)((0x100000000ull + (uint64_t)ntx - 1) / (uint64_t)ntx) : 0u;
             const int gx = c->me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
-            hipLaunchKernelGGL(k_me_pool, dim3(gx, 1, n_items), dim3(512), 0, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd);
+            hipLaunchKernelGGL(k_me_pool, dim3(gx, 1, n_items), dim3(512), 0, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse ? 1 : 0);
         }
         prof_end(c, s1);
         const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */
         if (flags_mbs) {
             prof_begin(c, KID_MEFIX, s1);
-            hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S);
+            hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S, fuse ? 1 : 0);
             prof_end(c, s1);
         }
 #ifdef VENC_LEGACY_KERNELS
@@ -649,12 +706,30 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             prof_end(c, s1);
         } else
 #endif
-        {
+        if (!fuse) {
             /* luma transform and chroma transform: independent blocks of one launch */
             const int n_luma = (band_mbs + 15) / 16, n_chroma = (band_mbs + 31) / 32;
             prof_begin(c, KID_INTER, s1);
             hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, b, S, n_luma);
             prof_end(c, s1);
+        } else {
+            /* The main chain ends here: search + luma transform, the flagged macroblocks' redo.  The next step's search
+             * needs nothing else (it reads luma only).  The chroma transform follows on the second stream, beside that
+             * search and ahead of the entropy chain of its batch; chroma reconstructions chain from step to step there. */
+            hipStream_t s2 = c->overlap ? c->stream2 : c->stream;
+            if (c->overlap) {
+                hipEvent_t el = c->ev_luma[c->ev_luma_next];
+                c->ev_luma_next ^= 1;
+                HIP_OK(hipEventRecord(el, s1));
+                HIP_OK(hipStreamWaitEvent(s2, el, 0));
+            }
+            prof_begin(c, KID_INTER, s2);
+            hipLaunchKernelGGL(k_inter_fused, dim3((band_mbs + 31) / 32, 1, n_items), dim3(256), 0, s2, g, b, S, 0);
+            prof_end(c, s2);
+            if (c->overlap) {
+                HIP_OK(hipEventRecord(c->ev_chroma, s2));
+                c->chroma_pending = 1;
+            }
         }
     }
 #ifdef VENC_LEGACY_KERNELS
@@ -665,37 +740,88 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         prof_end(c, s1);
     }
 #endif
-    if (c->overlap) {
-        HIP_OK(hipEventRecord(c->ev_main[p], s1));
-        HIP_OK(hipStreamWaitEvent(s2, c->ev_main[p], 0));
-    }
-    prof_begin(c, KID_CAVLC, s2);
-    if (is_idr)
-        hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, n_items), dim3(256), 0, s2, g, b, S);
-    else {
-        hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, n_items), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
-        /* one lane per listed unit: at most 7 per macroblock, about 1.2 on ordinary content -- blocks loop over the list */
-        const int cav_threads = (long long)band_mbs * n_items <= 131072 ? CAVLC_P_MAX_THREADS : 512;
-        const int cav_need = (7 * band_mbs + cav_threads - 1) / cav_threads;
-        const int cav_blocks = cav_need < CAVLC_P_BLOCK_LANES / cav_threads ? cav_need : CAVLC_P_BLOCK_LANES / cav_threads;
-        hipLaunchKernelGGL(k_cavlc_p, dim3(cav_blocks, 1, n_items), dim3(cav_threads), (size_t)cav_threads * 36, s2, g, b, S);
-    }
-    prof_end(c, s2);
-    if (c->overlap) {
-        HIP_OK(hipEventRecord(c->ev_side[rs], s2));
-        c->side_step[rs] = c->step_no;
-    }
-    prof_begin(c, KID_SCAN, s2);
-    hipLaunchKernelGGL(k_scan, dim3(band_slices, n_items), dim3(64 * SCAN_WAVES), 0, s2, g, b, S, c->d_slice);
-    prof_end(c, s2);
-    prof_begin(c, KID_PACK, s2);
-    hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, band_slices, n_items), dim3(256), 0, s2, g, b, S,
-                       (const venc_slice_out *)c->d_slice);
-    prof_end(c, s2);
     HIP_OK(hipGetLastError());
+    /* the step joins the entropy batch as (step, item) pairs k * max_items + i */
+    if (c->eb_n == 0) {
+        c->eb_S = S;
+        c->eb_first_slot = rs;
+        c->eb_first_step = c->step_no;
+    }
+    {
+        const int k = c->eb_n, G = c->cfg.max_items;
+        for (int i = 0; i < n_items; i++) {
+            c->eb_S.out_slot[k * G + i] = S.out_slot[i];
+            c->eb_S.idr_id[k * G + i] = S.idr_id[i];
+            c->eb_S.fnum[k * G + i] = (uint8_t)(frame_num & 15);
+        }
+        c->eb_n++;
+    }
     c->parity ^= 1;
     c->step_no++;
     c->steps_done++;
+    /* closed: I pictures (their own kernel), ragged steps, the last slot of the group, a full batch */
+    if (is_idr || n_items != c->cfg.max_items || c->eb_n == c->eb_max || (rs + 1) % c->eb_max == 0) return entropy_flush(c);
+    return 0;
+}
+
+/* launches the entropy chain of the open batch (second stream, behind the batch's main chains) */
+static int entropy_flush(venc_ctx *c) {
+    if (c->eb_n == 0) return 0;
+    HIP_OK(hipSetDevice(c->cfg.device));
+    const venc_geom &g = c->g;
+    const int G = c->cfg.max_items;
+    const size_t GN = (size_t)c->b.max_items * g.nmb;
+    venc_step S = c->eb_S;
+    const int n_steps = c->eb_n, rs0 = c->eb_first_slot;
+    const int nv = n_steps == 1 ? S.n_items : n_steps * G; /* (step, item) pairs; a batch of several steps has max_items each */
+    S.n_items = nv;
+    const int is_idr = S.is_idr;
+    const int band_mbs = S.mb1 - S.mb0, band_slices = S.slice1 - S.slice0;
+    venc_bufs b = c->b;
+    b.mvsad = c->b.mvsad + (size_t)rs0 * GN;
+    b.levels = c->b.levels + (size_t)rs0 * GN * VENC_MB_COEFS;
+    b.mbinfo = c->b.mbinfo + (size_t)rs0 * GN;
+    b.unit_count = c->b.unit_count + (size_t)c->unit_phase * c->b.vcap * VENC_COUNTER_STRIDE;
+    b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.vcap * VENC_COUNTER_STRIDE;
+    if (!is_idr) c->unit_phase ^= 1;
+    hipStream_t s1 = c->stream, s2 = c->overlap ? c->stream2 : c->stream;
+    if (c->overlap) {
+        hipEvent_t em = c->ev_main[c->ev_main_next];
+        c->ev_main_next ^= 1;
+        HIP_OK(hipEventRecord(em, s1));
+        HIP_OK(hipStreamWaitEvent(s2, em, 0));
+    }
+    prof_begin(c, KID_CAVLC, s2);
+    if (is_idr)
+        hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, nv), dim3(256), 0, s2, g, b, S);
+    else {
+        hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, nv), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
+        /* one lane per listed unit: at most 7 per macroblock, about 1.2 on ordinary content -- blocks loop over the list */
+        const int cav_threads = (long long)band_mbs * G <= 131072 ? CAVLC_P_MAX_THREADS : 512;
+        const int cav_need = (7 * band_mbs + cav_threads - 1) / cav_threads;
+        const int cav_blocks = cav_need < CAVLC_P_BLOCK_LANES / cav_threads ? cav_need : CAVLC_P_BLOCK_LANES / cav_threads;
+        hipLaunchKernelGGL(k_cavlc_p, dim3(cav_blocks, 1, nv), dim3(cav_threads), (size_t)cav_threads * 36, s2, g, b, S);
+    }
+    prof_end(c, s2);
+    if (c->overlap) {
+        /* the ring slots of the batch are free again once these kernels are done (k_scan and k_pack read the chain's own buffers) */
+        for (int k = 0; k < n_steps; k++) {
+            HIP_OK(hipEventRecord(c->ev_side[rs0 + k], s2));
+            c->side_step[rs0 + k] = c->eb_first_step + k;
+        }
+    }
+    prof_begin(c, KID_SCAN, s2);
+    hipLaunchKernelGGL(k_scan, dim3(band_slices, nv), dim3(64 * SCAN_WAVES), 0, s2, g, b, S, c->d_slice);
+    prof_end(c, s2);
+    prof_begin(c, KID_PACK, s2);
+    hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, band_slices, nv), dim3(256), 0, s2, g, b, S,
+                       (const venc_slice_out *)c->d_slice);
+    prof_end(c, s2);
+    HIP_OK(hipGetLastError());
+    /* tickets handed out while the batch was open complete here */
+    for (int i = 0; i < c->eb_nt; i++) HIP_OK(hipEventRecord(c->ev[c->eb_tickets[i] % c->n_events], s2));
+    c->eb_nt = 0;
+    c->eb_n = 0;
     return 0;
 }
 
@@ -710,6 +836,7 @@ extern "C" int venc_set_band(venc_ctx *c, int slice_first, int slice_count) {
         SET_ERR("venc_set_band: the diagnostic kernels (VENC_ME=plane, VENC_INTER=legacy) code whole pictures only");
         return -1;
     }
+    if (entropy_flush(c) != 0) return -1;
     c->band_s0 = slice_first;
     c->band_s1 = slice_first + slice_count;
     return 0;
@@ -767,6 +894,7 @@ static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride
         return -1;
     }
     HIP_OK(hipSetDevice(c->cfg.device));
+    HIP_OK(main_waits_for_chroma(c));
     J.to_chunk = to_chunk;
     J.item_stride = item_stride;
     uint32_t big = 0;
@@ -793,10 +921,20 @@ extern "C" void *venc_stream_handle(venc_ctx *c) { return (void *)c->stream; }
 
 extern "C" int venc_mark(venc_ctx *c) {
     const int t = c->ev_next;
-    HIP_OK(hipEventRecord(c->ev[t % c->n_events], c->overlap ? c->stream2 : c->stream));
+    if (c->eb_n > 0) {
+        /* the entropy chain of the steps issued so far is not launched yet: the ticket completes with the batch */
+        if (c->eb_nt >= (int)(sizeof(c->eb_tickets) / sizeof(c->eb_tickets[0])) && entropy_flush(c) != 0) return -1;
+    }
+    if (c->eb_n > 0)
+        c->eb_tickets[c->eb_nt++] = t;
+    else
+        HIP_OK(hipEventRecord(c->ev[t % c->n_events], c->overlap ? c->stream2 : c->stream));
     c->ev_next++;
     return t;
 }
+/* launches whatever the engine has deferred (the open entropy batch): after this everything issued completes without
+ * further calls.  venc_wait / venc_sync / venc_debug_read do it themselves; a caller that polls needs it. */
+extern "C" int venc_flush(venc_ctx *c) { return entropy_flush(c); }
 extern "C" int venc_wait(venc_ctx *c, int ticket) {
     if (ticket < 0 || ticket >= c->ev_next || c->ev_next - ticket > c->n_events) {
         SET_ERR("venc_wait: stale ticket %d", ticket);
@@ -805,11 +943,13 @@ extern "C" int venc_wait(venc_ctx *c, int ticket) {
     /* tickets complete in order (one stream records them): the frames of a step share a ticket, and a later ticket
      * that has been waited for covers the earlier ones -- no second trip into the runtime for them */
     if (ticket <= c->ev_done) return 0;
+    if (c->eb_nt > 0 && ticket >= c->eb_tickets[0] && entropy_flush(c) != 0) return -1; /* its batch is still open */
     HIP_OK(hipEventSynchronize(c->ev[ticket % c->n_events]));
     c->ev_done = ticket;
     return 0;
 }
 extern "C" int venc_sync(venc_ctx *c) {
+    if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream_copy));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
@@ -819,8 +959,10 @@ extern "C" int venc_sync(venc_ctx *c) {
 /* 1 (default): the entropy chain of a step runs on a second stream beside the next step's main
  * chain; 0: every kernel on one stream (isolated per-kernel timings for the roofline report) */
 extern "C" int venc_set_overlap(venc_ctx *c, int enable) {
+    if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
+    c->chroma_pending = 0;
     c->overlap = enable ? 1 : 0;
     for (int i = 0; i < VENC_RING; i++) c->side_step[i] = -1; /* both streams are idle: nothing to wait for */
     return 0;
@@ -851,6 +993,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         return -1;
     }
     HIP_OK(hipSetDevice(c->cfg.device));
+    if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     const venc_geom &g = c->g;
@@ -941,6 +1084,7 @@ extern "C" int venc_profile_kernels(void) { return KID_COUNT; }
 extern "C" const char *venc_profile_name(int kid) { return kid >= 0 && kid < KID_COUNT ? k_kernel_names[kid] : ""; }
 /* sums the recorded launches per kernel (after a stream sync) and resets the log */
 extern "C" int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches) {
+    if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     for (int k = 0; k < KID_COUNT; k++) ms_sum[k] = 0.0, launches[k] = 0;

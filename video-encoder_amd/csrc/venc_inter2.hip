@@ -103,36 +103,16 @@ DEVFN void unpack4(uint32_t v, int *o) {
 }
 /* current 4x4 block: aligned dword rows inside the display area, clamped bytes on its edges */
 
-/* luma transform of macroblock mb with vector (dx, dy): 16 lanes, lane & 15 = luma4x4BlkIdx, lane & 48 = the
+/* residual, transform, quantisation, reconstruction and stores of one luma 4x4 block per lane from its current rows cq[]
+ * and predicted rows pq[] (four samples per dword): 16 lanes per macroblock, lane & 15 = luma4x4BlkIdx, lane & 48 = the
  * wave's group of 16; every lane of the wave calls this (ballots), `valid` guards the stores */
-DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy) {
+DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, const uint32_t cq[4],
+                           const uint32_t pq[4]) {
     const int blk = lane & 15, gbase = lane & 48;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
-    int cstride, pw, ph, rstride, wstride;
-    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    int wstride;
     uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
-
-    uint32_t cq[4], pq[4]; /* current and predicted rows, four samples per dword */
-    load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, cq);
-    const int x0 = px + dx, y0 = py + dy;
-    if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
-        const uint32_t sh = (uint32_t)(x0 & 3);
-        const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const uint32_t *r32 = (const uint32_t *)(rp + (size_t)y * rstride);
-            pq[y] = __builtin_amdgcn_alignbyte(r32[1], r32[0], sh);
-        }
-    } else {
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const uint8_t *row = ref + (size_t)clampi(y0 + y, 0, g.ch - 1) * rstride;
-            pq[y] = (uint32_t)row[clampi(x0, 0, g.cw - 1)] | ((uint32_t)row[clampi(x0 + 1, 0, g.cw - 1)] << 8) |
-                    ((uint32_t)row[clampi(x0 + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(x0 + 3, 0, g.cw - 1)] << 24);
-        }
-    }
     int res[16], w[16], lv[16], rr[16], nnz;
 #pragma unroll
     for (int y = 0; y < 4; y++) {
@@ -168,6 +148,37 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
             info->flags = 0;
         }
     }
+}
+
+/* luma transform of macroblock mb with vector (dx, dy), current and predicted samples fetched from memory */
+DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy) {
+    const int blk = lane & 15;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
+    int cstride, pw, ph, rstride;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+
+    uint32_t cq[4], pq[4]; /* current and predicted rows, four samples per dword */
+    load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, cq);
+    const int x0 = px + dx, y0 = py + dy;
+    if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
+        const uint32_t sh = (uint32_t)(x0 & 3);
+        const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint32_t *r32 = (const uint32_t *)(rp + (size_t)y * rstride);
+            pq[y] = __builtin_amdgcn_alignbyte(r32[1], r32[0], sh);
+        }
+    } else {
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            const uint8_t *row = ref + (size_t)clampi(y0 + y, 0, g.ch - 1) * rstride;
+            pq[y] = (uint32_t)row[clampi(x0, 0, g.cw - 1)] | ((uint32_t)row[clampi(x0 + 1, 0, g.cw - 1)] << 8) |
+                    ((uint32_t)row[clampi(x0 + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(x0 + 3, 0, g.cw - 1)] << 24);
+        }
+    }
+    luma_block_code(g, B, S, item, lane, mb, valid, cq, pq);
 }
 
 /* chroma transform of macroblock mb: 8 lanes, lane & 3 = block, (lane >> 2) & 1 = plane, lane & 56 = group of 8 */
@@ -293,6 +304,9 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
  * macroblock per block).  It fits the 80 VGPRs, but on a chip saturated with transform waves the search chain takes
  * ~45 us (12 us as a kernel of its own on an empty chip), longer than the 37 us transform, and its prologue spills
  * cost every block ~5 %: 1080p +1.7 %, 2160p -1.3 % -- noise.  Dropped. */
+/* n_luma == 0: chroma only -- the shipped P step: the luma transform runs inside the motion search (k_me_pool P5, k_me_fix),
+ * this launch follows on the second stream beside the next step's search.  n_luma > 0: both (the legacy test library's
+ * searches do not transform). */
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_inter_fused(venc_geom g, venc_bufs B, venc_step S, int n_luma) {
     const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int bx = blockIdx.x;
@@ -304,7 +318,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const uint32_t m = mvs[mb];
         inter_chroma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u));
     } else {
-        if (bx == 0 && tid == 0) B.fix_count[item] = 0; /* consumed by k_me_fix; ready for the next step's motion search */
         const int mb_raw = S.mb0 + bx * 16 + (tid >> 4);
         const bool valid = mb_raw < S.mb1;
         const int mb = valid ? mb_raw : S.mb1 - 1;

@@ -74,6 +74,10 @@ typedef struct {
     int in_slot[VENC_MAX_ITEMS];
     int out_slot[VENC_MAX_ITEMS];
     int idr_id[VENC_MAX_ITEMS];
+    /* The entropy chain (k_skip / k_cavlc_p / k_cavlc, k_scan, k_pack) is launched once for up to four consecutive P steps
+     * ("entropy batch", venc_hip.hip): its grid's item index then runs over (step, item) pairs, v = k * max_items + item,
+     * and the per-item fields above and this one are indexed by v.  fnum[v] = frame_num of the step v belongs to. */
+    uint8_t fnum[VENC_MAX_ITEMS];
 } venc_step;
 
 #define VENC_COUNTER_STRIDE 32 /* words between per-item atomic counters: one cache line each */
@@ -84,6 +88,7 @@ typedef struct {
     uint8_t *recon; /* [2][G] frames */
     size_t recon_frame_bytes;
     int max_items;
+    int vcap;        /* (step, item) pairs the entropy chain's per-item buffers hold: entropy batch x max_items */
     uint32_t *mvsad;
     const uint32_t *mvsad_prev; /* vectors of the previous step (temporal predictor of the motion search) */
     int16_t *levels;
@@ -108,7 +113,9 @@ typedef struct {
     int *intra_rec;             /* [G][nmb][128] I pictures: block DCs + un-rounded edge samples (k_intra_fwd -> k_intra_dc) */
     int *intra_d0;              /* [G][nmb][32] I pictures: d0 + 64 pred + 32 per block (k_intra_dc -> k_intra_rec) */
     uint8_t *me_flag;           /* [G][nmb] 1 = k_me_tile left this macroblock to k_me_fix */
-    uint32_t *fix_count;        /* [G] flagged macroblocks of the step (zero at open; re-zeroed by k_inter_fused after k_me_fix) */
+    uint32_t *fix_count;        /* [G] flagged macroblocks of the step.  Two sets alternate between P steps (the launcher sets both
+                                   pointers): the search of a step zeroes the other set, which the next step's search fills */
+    uint32_t *fix_count_next;
     uint32_t *fix_list;         /* [G][nmb] their indices */
     unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */

@@ -689,7 +689,7 @@ DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int i
     venc_bs_ue(bs, (uint32_t)mb);
     venc_bs_ue(bs, S.is_idr ? 7u : 5u);
     venc_bs_ue(bs, 0);
-    venc_bs_put(bs, (uint32_t)S.frame_num & 15u, 4);
+    venc_bs_put(bs, (uint32_t)S.fnum[item] & 15u, 4);
     if (S.is_idr) {
         venc_bs_ue(bs, (uint32_t)S.idr_id[item]);
         venc_bs_put(bs, 0, 2); /* no_output_of_prior_pics, long_term_reference */

@@ -304,10 +304,11 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
 #define FIX_WD 13 /* window row: 48 bytes + 4 spare, in dwords */
 #define FIX_NDY 9
 
-__global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_step S) {
+__global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_step S, int fuse_luma) {
     __shared__ uint32_t s_win[(48 + 4) * FIX_WD];
     __shared__ uint32_t s_cur[16 * 4];
     __shared__ uint32_t s_best[4];
+    __shared__ int s_mv[2];
     const int item = blockIdx.z, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
@@ -394,6 +395,25 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
         if (mine == best) {
             const int dx = dxi - 16, dy = dy0 + mine_k - 16;
             B.mvsad[(size_t)item * g.nmb + mb] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+            s_mv[0] = dxi, s_mv[1] = dy0 + mine_k; /* window position of the winner */
+        }
+        if (fuse_luma) {
+            /* the luma transform of this macroblock (k_me_pool left it out with the search), from the window and the
+             * current block already in LDS: lanes 0-15 of wave 0, one 4x4 block each */
+            __syncthreads();
+            if (tid < 64) {
+                const int blk = lane & 15, bx = blk_x(blk) * 4, by = blk_y(blk) * 4;
+                const int boff = s_mv[0] + bx;
+                const uint32_t sh = (uint32_t)(boff & 3);
+                const uint32_t *wp = s_win + (s_mv[1] + by) * FIX_WD + (boff >> 2);
+                uint32_t cq[4], pq[4];
+#pragma unroll
+                for (int y = 0; y < 4; y++) {
+                    cq[y] = s_cur[(by + y) * 4 + (bx >> 2)];
+                    pq[y] = __builtin_amdgcn_alignbyte(wp[y * FIX_WD + 1], wp[y * FIX_WD], sh);
+                }
+                luma_block_code(g, B, S, item, lane, mb, lane < 16, cq, pq);
+            }
         }
     }
 }

@@ -77,14 +77,17 @@ DEVFN uint32_t me3_quarter_sad(const uint32_t *s_win, const uint32_t *s_cur, int
     return a;
 }
 
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_me_pool(venc_geom g, venc_bufs B, venc_step S, int tiles_x, int tiles_y, uint32_t tx_magic, int xcd_runs) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_me_pool(venc_geom g, venc_bufs B, venc_step S, int tiles_x, int tiles_y, uint32_t tx_magic, int xcd_runs, int fuse_luma) {
     __shared__ __attribute__((aligned(16))) uint32_t s_win[T2_WR * T2_WD];
     __shared__ __attribute__((aligned(16))) uint32_t s_cur[T2_MBY * 16 * T3_CW];
     /* horizontal sums (P1 -> P2), then, after a barrier, the vertical pairs built from them (P2 -> P3) */
     __shared__ __attribute__((aligned(16))) uint4 s_hv[T2_VR * T2_HG];
     __shared__ uint32_t s_pool[T3_POOL];
     static_assert(8 * 2 * T3_CAP <= T3_POOL, "eight wave segments of two macroblocks each");
-    __shared__ uint32_t s_best[T2_MBX * T2_MBY];
+    /* running best per macroblock: ((SAD << 11 | rank) << 11) | candidate index -- ordered like the search's key (the
+     * rank is unique), and the winner's displacement comes out of the same word: no rank -> candidate table, no global
+     * load at the tail of the block */
+    __shared__ __attribute__((aligned(8))) unsigned long long s_best[T2_MBX * T2_MBY];
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[8]; /* entries in each wave's pool segment */
     __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int kx = (int)(blockIdx.x >> 3);
     const int tile = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
     if (tile >= tiles_x * tiles_y) return;
+    if (tile == 0 && threadIdx.x == 0) B.fix_count_next[item] = 0; /* the other counter: the next P step's search fills it, nobody reads it now */
     /* tx_magic = ceil(2^32 / tiles_x), exact for these sizes; 0 stands for tiles_x == 1 (2^32 does not fit) */
     const int ty = tx_magic ? (int)__umulhi((uint32_t)tile, tx_magic) : tile, tx = tile - ty * tiles_x;
     const int x0 = tx * T2_MBX * 16, y0 = (S.row0 + ty * T2_MBY) * 16;
@@ -310,7 +314,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const uint32_t sad_p = lane < 32 ? q0 : q2, sad_a = lane < 32 ? q1 : q3;
         thr = min(sad_p, sad_a);
         if (l32 == 0) {
-            s_best[hw] = min((sad_p << 11) | rank_p, (sad_a << 11) | rank_a);
+            const unsigned long long kp = ((unsigned long long)((sad_p << 11) | rank_p) << 11) | (uint32_t)ci_p;
+            const unsigned long long ka = ((unsigned long long)((sad_a << 11) | rank_a) << 11) | (uint32_t)ai;
+            s_best[hw] = kp < ka ? kp : ka;
             s_ovf[hw] = 0;
         }
     }
@@ -372,7 +378,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     __syncthreads();
     if (S.me_stop == 5) {
-        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = s_best[hw] << 5;
+        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = (uint32_t)(s_best[hw] >> 11) << 5;
         return;
     }
     /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves; survivor k of the tile is entry
@@ -397,24 +403,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const uint32_t e = found ? s_pool[sbase + (k - start)] : 0xffffffffu;
             const int ehw = (int)((e >> 11) & 15u), ci = (int)(e & 2047u);
             bool need = found;
-            if (need) need = s_ovf[ehw] == 0u && (e >> 15) <= (s_best[ehw] >> 11);
+            if (need) need = s_ovf[ehw] == 0u && (e >> 15) <= (uint32_t)(s_best[ehw] >> 22);
             if (__ballot(need) == 0ull) continue;
             const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
             const int ecol = need ? (ehw & (T2_MBX - 1)) * 16 : 0, erow = need ? (ehw >> 3) * 16 : 0;
             const uint32_t sad = me3_quarter_sad(s_win, s_cur, ecol, erow, lane, cx, cy);
-            if (need && (lane & 15) == 15) atomicMin(&s_best[ehw], (sad << 11) | rank[cy * 33 + cx]);
+            if (need && (lane & 15) == 15)
+                atomicMin(&s_best[ehw], ((unsigned long long)((sad << 11) | rank[cy * 33 + cx]) << 11) | (uint32_t)ci);
         }
     }
     __syncthreads();
     if (l32 == 0 && mb_valid) {
-        const uint32_t best = s_best[hw];
-        const uint32_t cand = B.me_cand[best & 2047u];
-        const int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
-        B.mvsad[mbidx] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+        const unsigned long long best = s_best[hw];
+        const uint32_t ci = (uint32_t)best & 2047u, bcy = ci / 33u;
+        const int dx = (int)(ci - bcy * 33u) - 16, dy = (int)bcy - 16;
+        B.mvsad[mbidx] = ((uint32_t)(best >> 22) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
         const bool overflow = mycnt > T3_CAP;
         B.me_flag[mbidx] = overflow ? 1 : 0; /* k_me_fix searches it exhaustively */
         if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(my * g.mbw + mx);
         B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
     }
+    }
+    /* ---- P5: the luma transform of the tile's macroblocks, straight from the LDS copies the search used: current samples
+     * from s_cur, prediction from the window at the winning displacement -> residual, 4x4 transform, quantisation,
+     * dequantisation, inverse transform, reconstruction, levels (venc_inter2.hip luma_block_code).  16 macroblocks x 16
+     * blocks = the lanes of waves 0-3; macroblocks listed for k_me_fix are left to it.  The transform no longer re-reads
+     * the two luma planes from memory and costs the main chain no launch of its own. ---- */
+    if (fuse_luma && threadIdx.x < 256) {
+        const int t5 = threadIdx.x, m = t5 >> 4, blk = t5 & 15;
+        const int mcol0 = (m & (T2_MBX - 1)) * 16, mrow0 = (m >> 3) * 16;
+        const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
+        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] == 0u;
+        const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
+        const int bx = blk_x(blk) * 4, by = blk_y(blk) * 4;
+        const int boff = mcol0 + (int)bcx + bx;
+        const uint32_t sh = (uint32_t)(boff & 3);
+        const uint32_t *wp = s_win + (mrow0 + (int)bcy + by) * T2_WD + (boff >> 2);
+        const uint32_t *cp = s_cur + (mrow0 + by) * T3_CW + ((mcol0 + bx) >> 2);
+        uint32_t cq[4], pq[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+            cq[y] = cp[y * T3_CW];
+            pq[y] = __builtin_amdgcn_alignbyte(wp[y * T2_WD + 1], wp[y * T2_WD], sh);
+        }
+        luma_block_code(g, B, S, item, t5 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, cq, pq);
     }
 }
