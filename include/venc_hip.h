@@ -131,13 +131,22 @@ void *venc_stream_handle(venc_ctx *c); /* hipStream_t of the main kernel chain *
 int venc_mark(venc_ctx *c);
 int venc_wait(venc_ctx *c, int ticket);
 int venc_flush(venc_ctx *c);
+/* For a second host thread (packaging beside launching): venc_bind_thread once on that thread; venc_wait_issued blocks
+ * until a ticket completes, provided venc_flush (or venc_wait) ran after the ticket was issued.  Both are safe beside
+ * venc_encode_step / venc_mark / venc_flush on another thread; every other function belongs to one thread at a time. */
+int venc_bind_thread(venc_ctx *c);
+int venc_wait_issued(venc_ctx *c, int ticket);
 int venc_sync(venc_ctx *c);
 /* 1 (default): the entropy kernels of a step (k_cavlc, k_scan, k_pack) run on a second HIP
  * stream beside the next step's motion/transform kernels; 0: one stream, no concurrency. */
 int venc_set_overlap(venc_ctx *c, int enable);
 
-/* Output of out slot `slot` (valid after the producing step completed). */
+/* Output of out slot `slot` (valid after the producing step completed).  Engines with max_items > 1 stage the encoded
+ * bytes in HBM; venc_get_frame brings a slot's bytes to pinned host memory when nobody has yet (one DMA copy and a
+ * wait per slot), venc_fetch does it for the `count` slots first_slot, first_slot + slot_step, ... with a single strided
+ * copy -- the slots of one lock-step frame of `count` GOPs, say. */
 int venc_get_frame(venc_ctx *c, int slot, venc_frame *out);
+int venc_fetch(venc_ctx *c, int first_slot, int slot_step, int count);
 
 /* Introspection for kernel-level parity tests: copies device intermediates of
  * chain `item` (state after the last step) to host memory.

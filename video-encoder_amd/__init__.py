@@ -144,6 +144,7 @@ def bind_hip(L):
                                        C.POINTER(C.c_int)]
         L.venc_wait.argtypes = [C.c_void_p, C.c_int]
         L.venc_get_frame.argtypes = [C.c_void_p, C.c_int, C.POINTER(VencFrame)]
+        L.venc_fetch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.venc_debug_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
         L.venc_synth_frame.restype = None
         L.venc_synth_frame.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -84,6 +84,8 @@ struct venc_ctx {
     int eb_first_slot;                /* ring slot of the first */
     long long eb_first_step;
     venc_step eb_S;                   /* per (step, item) fields of the batch */
+    venc_step eb_step[VENC_EBATCH];   /* the steps themselves: their chroma transforms are launched with the batch, one after the other */
+    int eb_chroma;                    /* the steps of the batch still owe their chroma transform */
     int eb_tickets[VENC_EBATCH * 2];  /* venc_mark() tickets issued while the batch was open: recorded at the flush */
     int eb_nt;
     int overlap;
@@ -95,7 +97,14 @@ struct venc_ctx {
     long long step_no; /* steps issued so far; ring slot of a step = step_no % VENC_RING */
     uint8_t *d_in;        /* internal input pool (may be null) */
     int in_frames;        /* frames addressable through b.in_base */
-    uint8_t *h_out;       /* pinned output pool (host view) */
+    uint8_t *h_hdr;       /* pinned, device-mapped: per out slot venc_out_header + slice table (k_scan writes it over PCIe: tens of bytes) */
+    uint8_t *h_data;      /* pinned host pool of the slots' data[] */
+    uint8_t *d_data;      /* staged engines: HBM buffer k_pack writes; venc_fetch copies the used bytes to h_data by DMA */
+    int staged;           /* max_items > 1 (VENC_STAGED=0/1 overrides): k_pack's stores to pinned host memory wait on PCIe and, worse,
+                             slow every other kernel's memory traffic while they drain (the search beside an I picture's k_pack ran at
+                             a quarter of its speed); HBM stores do neither, and the copy engine moves the bytes without a CU */
+    uint8_t *fetched;     /* [out_slots] staged engines: the slot's data is in h_data */
+    hipStream_t stream_d2h;
     venc_slice_out *d_slice;
     int *d_slice_rows;
     uint8_t *d_row_slice;
@@ -228,7 +237,11 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->d_row_slice);
     (void)hipFree(c->d_rank);
     (void)hipFree(c->d_cand);
-    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->h_hdr) (void)hipHostFree(c->h_hdr);
+    if (c->h_data) (void)hipHostFree(c->h_data);
+    (void)hipFree(c->d_data);
+    free(c->fetched);
+    if (c->stream_d2h) (void)hipStreamDestroy(c->stream_d2h);
     if (c->prof_ev)
         for (int i = 0; i < 2 * c->prof_cap; i++)
             if (c->prof_ev[i]) (void)hipEventDestroy(c->prof_ev[i]);
@@ -479,8 +492,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     b.me_rank = c->d_rank;
     b.me_cand = c->d_cand;
 
-    /* pinned, device-mapped output pool: header | slice table | data */
-    b.out_data_off = (uint32_t)((sizeof(venc_out_header) + (size_t)g.n_slices * sizeof(venc_slice_out) + 63) & ~(size_t)63);
+    /* output pool: headers + slice tables in pinned, device-mapped memory; data in HBM (staged) or pinned host memory */
+    b.out_hdr_stride = (sizeof(venc_out_header) + (size_t)g.n_slices * sizeof(venc_slice_out) + 63) & ~(size_t)63;
     /* Capacity per frame.  H.264 Annex A.3.1 caps macroblock_layer() at 3200 bits = 400 bytes per macroblock for the
      * Baseline family; a macroblock above that is not a conforming stream whatever the buffer holds (libx264 re-codes it as
      * I_PCM, a mode this subset does not have).  QP < 40 gets exactly that bound = 1.56 bytes per pixel.  Uniform white
@@ -490,12 +503,31 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
      * 256 bytes per macroblock (twice what noise needs there).  + slice headers and the per-slice 4-byte alignment.
      * Overflow is reported through header.error -> venc_get_frame() = -3, never silent. */
     b.out_cap = (uint32_t)((size_t)g.nmb * (cfg->qp < 40 ? 400 : 256) + (size_t)g.n_slices * 64 + 4096);
-    b.out_slot_bytes = ((size_t)b.out_data_off + b.out_cap + 255) & ~(size_t)255;
-    OPEN_OK(hipHostMalloc((void **)&c->h_out, b.out_slot_bytes * cfg->out_slots, hipHostMallocMapped));
-    for (int i = 0; i < cfg->out_slots; i++) memset(c->h_out + (size_t)i * b.out_slot_bytes, 0, b.out_data_off); /* header + slice table */
+    b.out_data_stride = ((size_t)b.out_cap + 255) & ~(size_t)255;
+    {
+        const char *e = getenv("VENC_STAGED");
+        c->staged = e ? atoi(e) != 0 : cfg->max_items > 1;
+    }
+    OPEN_OK(hipHostMalloc((void **)&c->h_hdr, b.out_hdr_stride * cfg->out_slots, hipHostMallocMapped));
+    memset(c->h_hdr, 0, b.out_hdr_stride * cfg->out_slots);
+    OPEN_OK(hipHostMalloc((void **)&c->h_data, b.out_data_stride * cfg->out_slots, c->staged ? hipHostMallocDefault : hipHostMallocMapped));
     void *dview = NULL;
-    OPEN_OK(hipHostGetDevicePointer(&dview, c->h_out, 0));
-    b.out_base = (uint8_t *)dview;
+    OPEN_OK(hipHostGetDevicePointer(&dview, c->h_hdr, 0));
+    b.out_hdr = (uint8_t *)dview;
+    if (c->staged) {
+        OPEN_OK(hipMalloc(&c->d_data, b.out_data_stride * cfg->out_slots));
+        b.out_data = c->d_data;
+        c->fetched = (uint8_t *)calloc((size_t)cfg->out_slots, 1);
+        if (!c->fetched) {
+            SET_ERR("venc_open: out of host memory");
+            venc_close(c);
+            return -1;
+        }
+        OPEN_OK(hipStreamCreateWithFlags(&c->stream_d2h, hipStreamNonBlocking));
+    } else {
+        OPEN_OK(hipHostGetDevicePointer(&dview, c->h_data, 0));
+        b.out_data = (uint8_t *)dview;
+    }
     OPEN_OK(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -622,6 +654,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         }
         S.in_slot[i] = in_slots[i];
         S.out_slot[i] = out_slots[i];
+        if (c->staged) c->fetched[out_slots[i]] = 0;
         if (c->d_in && c->b.in_base == c->d_in && c->copy_pending[in_slots[i]]) { /* the frame's ingest copy precedes the step */
             HIP_OK(hipStreamWaitEvent(c->stream, c->ev_copy[in_slots[i]], 0));
             c->copy_pending[in_slots[i]] = 0;
@@ -638,6 +671,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     b.levels = c->b.levels + (size_t)rs * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
     hipStream_t s1 = c->stream;
+    bool chroma_deferred = false;
     /* an open entropy batch takes this step only if it continues it: same kind of picture (P), same items, same band,
      * the next ring slot of the same aligned group */
     if (c->eb_n > 0 && !(!is_idr && !c->eb_S.is_idr && n_items == c->cfg.max_items && c->eb_S.slice0 == S.slice0 && c->eb_S.slice1 == S.slice1 &&
@@ -714,22 +748,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             prof_end(c, s1);
         } else {
             /* The main chain ends here: search + luma transform, the flagged macroblocks' redo.  The next step's search
-             * needs nothing else (it reads luma only).  The chroma transform follows on the second stream, beside that
-             * search and ahead of the entropy chain of its batch; chroma reconstructions chain from step to step there. */
-            hipStream_t s2 = c->overlap ? c->stream2 : c->stream;
-            if (c->overlap) {
-                hipEvent_t el = c->ev_luma[c->ev_luma_next];
-                c->ev_luma_next ^= 1;
-                HIP_OK(hipEventRecord(el, s1));
-                HIP_OK(hipStreamWaitEvent(s2, el, 0));
-            }
-            prof_begin(c, KID_INTER, s2);
-            hipLaunchKernelGGL(k_inter_fused, dim3((band_mbs + 31) / 32, 1, n_items), dim3(256), 0, s2, g, b, S, 0);
-            prof_end(c, s2);
-            if (c->overlap) {
-                HIP_OK(hipEventRecord(c->ev_chroma, s2));
-                c->chroma_pending = 1;
-            }
+             * needs nothing else (it reads luma only).  The chroma transforms of a batch of steps follow on the second
+             * stream, one after the other (chroma reconstructions chain from step to step), ahead of the batch's entropy
+             * chain and beside the next searches: ONE event hand-off per batch, none between the kernels of the main chain. */
+            chroma_deferred = true;
         }
     }
 #ifdef VENC_LEGACY_KERNELS
@@ -754,6 +776,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             c->eb_S.idr_id[k * G + i] = S.idr_id[i];
             c->eb_S.fnum[k * G + i] = (uint8_t)(frame_num & 15);
         }
+        c->eb_step[k] = S;
+        if (k == 0) c->eb_chroma = 0;
+        if (chroma_deferred) c->eb_chroma = 1;
         c->eb_n++;
     }
     c->parity ^= 1;
@@ -790,6 +815,23 @@ static int entropy_flush(venc_ctx *c) {
         c->ev_main_next ^= 1;
         HIP_OK(hipEventRecord(em, s1));
         HIP_OK(hipStreamWaitEvent(s2, em, 0));
+    }
+    if (c->eb_chroma) {
+        for (int k = 0; k < n_steps; k++) {
+            venc_bufs bk = c->b;
+            const int rsk = rs0 + k;
+            bk.mvsad = c->b.mvsad + (size_t)rsk * GN;
+            bk.levels = c->b.levels + (size_t)rsk * GN * VENC_MB_COEFS;
+            bk.mbinfo = c->b.mbinfo + (size_t)rsk * GN;
+            prof_begin(c, KID_INTER, s2);
+            hipLaunchKernelGGL(k_inter_fused, dim3((band_mbs + 31) / 32, 1, c->eb_step[k].n_items), dim3(256), 0, s2, g, bk, c->eb_step[k], 0);
+            prof_end(c, s2);
+        }
+        if (c->overlap) {
+            HIP_OK(hipEventRecord(c->ev_chroma, s2));
+            c->chroma_pending = 1;
+        }
+        c->eb_chroma = 0;
     }
     prof_begin(c, KID_CAVLC, s2);
     if (is_idr)
@@ -894,6 +936,7 @@ static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride
         return -1;
     }
     HIP_OK(hipSetDevice(c->cfg.device));
+    if (entropy_flush(c) != 0) return -1; /* (the chroma transforms of an open batch are launched with it) */
     HIP_OK(main_waits_for_chroma(c));
     J.to_chunk = to_chunk;
     J.item_stride = item_stride;
@@ -948,6 +991,21 @@ extern "C" int venc_wait(venc_ctx *c, int ticket) {
     c->ev_done = ticket;
     return 0;
 }
+/* Thread-safe subset for a second host thread (the shim's packaging thread): bind the device once, then wait for tickets
+ * whose work has already been handed to the GPU (venc_flush / venc_wait was called after the ticket was issued).  Touches
+ * no engine state. */
+extern "C" int venc_bind_thread(venc_ctx *c) {
+    HIP_OK(hipSetDevice(c->cfg.device));
+    return 0;
+}
+extern "C" int venc_wait_issued(venc_ctx *c, int ticket) {
+    if (ticket < 0) {
+        SET_ERR("venc_wait_issued: bad ticket %d", ticket);
+        return -1;
+    }
+    HIP_OK(hipEventSynchronize(c->ev[ticket % c->n_events]));
+    return 0;
+}
 extern "C" int venc_sync(venc_ctx *c) {
     if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream_copy));
@@ -968,14 +1026,49 @@ extern "C" int venc_set_overlap(venc_ctx *c, int enable) {
     return 0;
 }
 
+/* Staged engines: copy the encoded bytes of `count` output slots first_slot, first_slot + slot_step, ... (frames whose step
+ * has completed -- the caller waited for their ticket) from the HBM staging buffer to the pinned host pool: ONE strided DMA
+ * copy of the widest frame's byte count per slot, on a stream of its own, then a wait.  No-op for slots already fetched and
+ * in direct engines.  Safe on the packaging thread beside venc_encode_step on another thread (a slot is reused only after
+ * its frame was delivered). */
+extern "C" int venc_fetch(venc_ctx *c, int first_slot, int slot_step, int count) {
+    if (!c->staged) return 0;
+    if (count < 1 || first_slot < 0 || slot_step < 1 || first_slot + (count - 1) * slot_step >= c->cfg.out_slots) {
+        SET_ERR("venc_fetch: bad slot range (%d, step %d, count %d)", first_slot, slot_step, count);
+        return -1;
+    }
+    uint32_t widest = 0;
+    int need = 0;
+    for (int i = 0; i < count; i++) {
+        const int slot = first_slot + i * slot_step;
+        const venc_out_header *h = (const venc_out_header *)(c->h_hdr + (size_t)slot * c->b.out_hdr_stride);
+        if (c->fetched[slot] || h->error) continue;
+        need++;
+        if (h->total_bytes > widest) widest = h->total_bytes;
+    }
+    if (!need) return 0;
+    if (widest > c->b.out_cap) widest = c->b.out_cap;
+    if (widest) {
+        const size_t off = (size_t)first_slot * c->b.out_data_stride, pitch = (size_t)slot_step * c->b.out_data_stride;
+        if (count == 1)
+            HIP_OK(hipMemcpyAsync(c->h_data + off, c->d_data + off, widest, hipMemcpyDeviceToHost, c->stream_d2h));
+        else
+            HIP_OK(hipMemcpy2DAsync(c->h_data + off, pitch, c->d_data + off, pitch, widest, (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+        HIP_OK(hipStreamSynchronize(c->stream_d2h));
+    }
+    for (int i = 0; i < count; i++) c->fetched[first_slot + i * slot_step] = 1;
+    return 0;
+}
+
 extern "C" int venc_get_frame(venc_ctx *c, int slot, venc_frame *out) {
     if (slot < 0 || slot >= c->cfg.out_slots || !out) {
         SET_ERR("venc_get_frame: bad slot %d", slot);
         return -1;
     }
-    const uint8_t *p = c->h_out + (size_t)slot * c->b.out_slot_bytes;
+    const uint8_t *p = c->h_hdr + (size_t)slot * c->b.out_hdr_stride;
     const venc_out_header *h = (const venc_out_header *)p;
-    out->data = p + c->b.out_data_off;
+    if (c->staged && !c->fetched[slot] && !h->error && venc_fetch(c, slot, 1, 1) != 0) return -1;
+    out->data = c->h_data + (size_t)slot * c->b.out_data_stride;
     out->slices = (const venc_slice *)(p + sizeof(venc_out_header));
     out->n_slices = h->n_slices;
     out->total_bytes = h->total_bytes;

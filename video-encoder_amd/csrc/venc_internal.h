@@ -11,7 +11,9 @@
  *   mbbits        [G][nmb][VENC_MB_WORDS] u32  MSB-first bit strings, one per syntax unit (unit u at word 64 u)
  *   mbnbits/mboff [G][nmb] u32
  *   refsum        [G][ch+25][cw+17 (padded)] u32 = S8(x,y) | S8(x+8,y)<<16 of the reference luma
- *   out (pinned host, device-mapped) [out_slots][out_cap] bytes + slice table
+ *   out headers (pinned host, device-mapped) [out_slots][header | slice table]
+ *   out data    [out_slots][out_cap]: HBM staging, fetched to a pinned host pool by DMA (batched engines), or the
+ *               device view of that host pool itself (one-item engines: lowest latency)
  */
 #ifndef VENC_INTERNAL_H
 #define VENC_INTERNAL_H
@@ -119,9 +121,10 @@ typedef struct {
     uint32_t *fix_list;         /* [G][nmb] their indices */
     unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
-    uint8_t *out_base;          /* device view of the pinned output pool */
-    size_t out_slot_bytes;
-    uint32_t out_data_off;      /* offset of data[] inside a slot */
+    uint8_t *out_hdr;           /* device view of the pinned header pool: per slot venc_out_header + slice table */
+    size_t out_hdr_stride;
+    uint8_t *out_data;          /* per slot data[]: HBM staging buffer, or the device view of the pinned host pool */
+    size_t out_data_stride;
     uint32_t out_cap;           /* capacity of data[] */
 } venc_bufs;
 

@@ -977,7 +977,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_scan(venc_geom g, venc_bufs
         if (s_last) {
             __threadfence();
             B.scan_done[item * VENC_COUNTER_STRIDE] = 0; /* for the next step (same stream: ordered) */
-            uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
+            uint8_t *slot = B.out_hdr + (size_t)S.out_slot[item] * B.out_hdr_stride;
             venc_slice_out *host_tab = (venc_slice_out *)(slot + sizeof(venc_out_header));
             uint32_t byte_off = 0;
             for (int k = 0; k < g.n_slices; k++) {
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_scan(venc_geom g, venc_bufs
  * Owner-gather: output word w of a slice (stream bits [32w, 32w+32)) is built by
  * the macroblock that contains bit 32w, reading on into the following
  * macroblocks' bit strings as needed.  No atomics, no pre-zeroed destination;
- * the destination is the device view of pinned host memory. */
+ * the destination is the HBM staging buffer of the output slot (or, in one-item engines, the device view of pinned host memory). */
 DEVFN uint32_t fetch_bits(const uint32_t *wds, int pos, int n) { /* 1 <= n <= 32 */
     const int wi = pos >> 5, shb = pos & 31;
     const uint64_t two = ((uint64_t)wds[wi] << 32) | (uint64_t)((shb + n > 32) ? wds[wi + 1] : 0u);
@@ -1029,8 +1029,7 @@ __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_ste
     const uint4 *endp = (const uint4 *)(B.ubits + (size_t)item * g.nmb * 8);
     const uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     const uint32_t *bits = B.mbbits + (size_t)item * g.nmb * VENC_MB_WORDS;
-    uint8_t *slot = B.out_base + (size_t)S.out_slot[item] * B.out_slot_bytes;
-    uint32_t *out = (uint32_t *)(slot + B.out_data_off + so.byte_off);
+    uint32_t *out = (uint32_t *)(B.out_data + (size_t)S.out_slot[item] * B.out_data_stride + so.byte_off);
     if (tid < n_here) {
         s_off[tid] = offp[m0 + tid];
         s_end[tid] = endp[m0 + tid];

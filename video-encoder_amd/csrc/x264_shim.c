@@ -25,6 +25,7 @@
 #include "../../include/x264.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <time.h>
 #include <stdlib.h>
@@ -40,7 +41,7 @@ typedef struct {
     int is_idr;
     int out_slot;
     int ticket;
-    int assembled;      /* NALs of this frame are packaged in payload[] */
+    volatile int assembled; /* NALs of this frame are packaged in payload[] (gop_batch > 1: set by the packaging thread under mtx) */
     uint8_t *payload;   /* grown on demand, reused by the next frame that maps to this ring entry */
     size_t payload_cap;
     int payload_size;
@@ -64,6 +65,16 @@ struct x264_t {
     double trace_t0;    /* VENC_TRACE: start of the resident call (0 = no trace) */
     int64_t ext_clip;   /* resident mode: frames in the resident clip; stream frame f reads clip frame f % ext_clip */
     int band_first, band_count; /* slices coded by this encoder (slice-parallel mode), 0/0 = all */
+    /* gop_batch > 1: NAL packaging (the wait for the GPU, emulation prevention, length prefixes: ~1.9 ms per 300-frame
+     * 1080p unit) runs on a thread of its own, in the order the GPU completes frames, beside the caller's thread, which
+     * launches units and hands frames to the sink in display order.  The reference's caller stays single-threaded: it
+     * sees frames only through x264_encoder_encode / the sink, on its own thread. */
+    pthread_t worker;
+    int worker_on;
+    pthread_mutex_t mtx;
+    pthread_cond_t cv_work, cv_done;
+    volatile int64_t w_launched; /* copy of n_launched for the worker (under mtx) */
+    volatile int w_stop, w_err;
 };
 
 /* slice-parallel mode: let the bands' owners swap reconstructed rows before the next P picture */
@@ -78,6 +89,8 @@ static double now_ms(void) {
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
 }
+
+static void *packaging_thread(void *arg);
 
 static const char *const k_presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast",
                                         "medium",    "slow",      "slower",   "veryslow", "placebo", NULL};
@@ -227,11 +240,35 @@ x264_t *x264_encoder_open(x264_param_t *param) {
             return NULL;
         }
     }
+    /* a packaging thread for GOP-batched encoders (VENC_HOST_THREADS=1 keeps everything on the caller's thread) */
+    if (h->gop_batch > 1 && !(getenv("VENC_HOST_THREADS") && atoi(getenv("VENC_HOST_THREADS")) <= 1)) {
+        pthread_mutex_init(&h->mtx, NULL);
+        pthread_cond_init(&h->cv_work, NULL);
+        pthread_cond_init(&h->cv_done, NULL);
+        h->worker_on = 1;
+        if (pthread_create(&h->worker, NULL, packaging_thread, h) != 0) {
+            h->worker_on = 0;
+            pthread_mutex_destroy(&h->mtx);
+            pthread_cond_destroy(&h->cv_work);
+            pthread_cond_destroy(&h->cv_done);
+        }
+    }
     return h;
 }
 
 void x264_encoder_close(x264_t *h) {
     if (!h) return;
+    if (h->worker_on) {
+        pthread_mutex_lock(&h->mtx);
+        h->w_stop = 1;
+        pthread_cond_broadcast(&h->cv_work);
+        pthread_mutex_unlock(&h->mtx);
+        pthread_join(h->worker, NULL);
+        pthread_mutex_destroy(&h->mtx);
+        pthread_cond_destroy(&h->cv_work);
+        pthread_cond_destroy(&h->cv_done);
+        h->worker_on = 0;
+    }
     venc_close(h->ctx);
     if (h->ring)
         for (int i = 0; i < h->pool; i++) {
@@ -285,6 +322,13 @@ static int launch_pending(x264_t *h, int flush) {
             h->gop_counter += gops;
         }
         h->n_launched += n;
+        if (h->worker_on) {
+            if (venc_flush(h->ctx) != 0) return -1; /* every ticket of the unit is now recorded on the GPU's streams */
+            pthread_mutex_lock(&h->mtx);
+            h->w_launched = h->n_launched;
+            pthread_cond_signal(&h->cv_work);
+            pthread_mutex_unlock(&h->mtx);
+        }
     }
     return 0;
 }
@@ -293,7 +337,9 @@ static int launch_pending(x264_t *h, int flush) {
 static int assemble_frame(x264_t *h, int64_t f) {
     shim_frame *fr = &h->ring[f % h->pool];
     if (fr->assembled) return 0;
-    if (venc_wait(h->ctx, fr->ticket) != 0) return -1;
+    /* the packaging thread only waits on tickets whose work has been flushed to the GPU (launch_pending ends every unit
+     * with venc_flush): venc_wait_issued touches no engine state */
+    if ((h->worker_on ? venc_wait_issued(h->ctx, fr->ticket) : venc_wait(h->ctx, fr->ticket)) != 0) return -1;
     venc_frame vf;
     if (venc_get_frame(h->ctx, fr->out_slot, &vf) != 0) return -1;
     const size_t need = 256 + (size_t)vf.n_slices * 16 + (size_t)vf.total_bytes * 3 / 2;
@@ -330,22 +376,73 @@ static int assemble_frame(x264_t *h, int64_t f) {
     }
     fr->n_nals = n;
     fr->payload_size = (int)o;
-    fr->assembled = 1;
+    if (h->worker_on) {
+        pthread_mutex_lock(&h->mtx);
+        fr->assembled = 1;
+        pthread_cond_broadcast(&h->cv_done);
+        pthread_mutex_unlock(&h->mtx);
+    } else
+        fr->assembled = 1;
     return 0;
+}
+
+static int assemble_next_unit(x264_t *h);
+
+/* packaging thread: units in launch order, frames of a unit in completion order */
+static void *packaging_thread(void *arg) {
+    x264_t *h = (x264_t *)arg;
+    (void)venc_bind_thread(h->ctx);
+    for (;;) {
+        pthread_mutex_lock(&h->mtx);
+        while (!h->w_stop && h->n_asm >= h->w_launched) pthread_cond_wait(&h->cv_work, &h->mtx);
+        const int stop = h->w_stop;
+        pthread_mutex_unlock(&h->mtx);
+        if (stop) break;
+        if (assemble_next_unit(h) != 0) {
+            pthread_mutex_lock(&h->mtx);
+            h->w_err = 1;
+            pthread_cond_broadcast(&h->cv_done);
+            pthread_mutex_unlock(&h->mtx);
+            break;
+        }
+    }
+    return NULL;
+}
+
+/* caller's thread: block until frame f is packaged (or the packaging thread failed) */
+static int wait_assembled(x264_t *h, int64_t f) {
+    shim_frame *fr = &h->ring[f % h->pool];
+    int err;
+    pthread_mutex_lock(&h->mtx);
+    while (!fr->assembled && !h->w_err) pthread_cond_wait(&h->cv_done, &h->mtx);
+    err = h->w_err;
+    pthread_mutex_unlock(&h->mtx);
+    return err ? -1 : 0;
 }
 
 /* package the oldest launched unit in the order its frames complete on the GPU
  * (frame index t of every GOP after step t), so the host works while later steps run */
 static int assemble_next_unit(x264_t *h) {
-    if (h->n_asm >= h->n_launched) return 0;
+    const int64_t launched = h->worker_on ? h->w_launched : h->n_launched;
+    if (h->n_asm >= launched) return 0;
     const int64_t base = h->n_asm;
-    const int64_t left = h->n_launched - base;
+    const int64_t left = launched - base;
     const int n = (int)(left < h->unit ? left : h->unit);
     if (h->gop_batch == 1) {
         if (assemble_frame(h, base) != 0) return -1;
     } else {
         const int gops = (n + h->keyint - 1) / h->keyint;
         for (int t = 0; t < h->keyint; t++) {
+            /* the frames of step t (one per GOP, keyint output slots apart): wait for the step, bring their bytes to the
+             * host with one strided copy (engines that stage their output in HBM), then package them */
+            int cnt = 0;
+            for (int g = 0; g < gops; g++)
+                if ((int64_t)g * h->keyint + t < n) cnt++;
+            if (cnt > 0) {
+                shim_frame *f0 = &h->ring[(base + t) % h->pool];
+                if ((h->worker_on ? venc_wait_issued(h->ctx, f0->ticket) : venc_wait(h->ctx, f0->ticket)) != 0) return -1;
+                if (venc_fetch(h->ctx, f0->out_slot, h->keyint, cnt) != 0) return -1;
+            }
             for (int g = 0; g < gops; g++) {
                 const int64_t k = (int64_t)g * h->keyint + t;
                 if (k < n && assemble_frame(h, base + k) != 0) return -1;
@@ -354,14 +451,20 @@ static int assemble_next_unit(x264_t *h) {
                 fprintf(stderr, "venc trace:     step %d of unit at frame %lld packaged at +%.3f ms\n", t, (long long)base, now_ms() - h->trace_t0);
         }
     }
-    h->n_asm += n;
+    if (h->worker_on) {
+        pthread_mutex_lock(&h->mtx);
+        h->n_asm += n;
+        pthread_cond_broadcast(&h->cv_done);
+        pthread_mutex_unlock(&h->mtx);
+    } else
+        h->n_asm += n;
     return 0;
 }
 
 /* hand frame n_out to the caller */
 static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_out) {
     shim_frame *fr = &h->ring[h->n_out % h->pool];
-    if (assemble_frame(h, h->n_out) != 0) return -1;
+    if ((h->worker_on ? wait_assembled(h, h->n_out) : assemble_frame(h, h->n_out)) != 0) return -1;
     if (pic_out) {
         pic_out->i_type = fr->is_idr ? X264_TYPE_IDR : X264_TYPE_P;
         pic_out->b_keyframe = fr->is_idr;
@@ -371,7 +474,7 @@ static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *
     *pp_nal = fr->nals;
     *pi_nal = fr->n_nals;
     h->n_out++;
-    if (h->n_asm < h->n_out) h->n_asm = h->n_out;
+    if (!h->worker_on && h->n_asm < h->n_out) h->n_asm = h->n_out;
     return fr->payload_size;
 }
 
@@ -405,6 +508,19 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
     return deliver(h, pp_nal, pi_nal, pic_out);
 }
 
+/* restart the frame numbering (resident calls; after a failed call).  The packaging thread is idle or is made idle first:
+ * it owns n_asm while units are in flight. */
+static void reset_counters(x264_t *h) {
+    if (h->worker_on) {
+        pthread_mutex_lock(&h->mtx);
+        while (h->n_asm < h->w_launched && !h->w_err) pthread_cond_wait(&h->cv_done, &h->mtx);
+        h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
+        h->w_launched = 0;
+        pthread_mutex_unlock(&h->mtx);
+    } else
+        h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
+}
+
 int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_stride, int n_frames, int64_t first_pts,
                               x264_venc_sink sink, void *user) {
     return x264_venc_encode_resident_loop(h, d_frames, frame_stride, n_frames, 1, first_pts, sink, user);
@@ -424,14 +540,15 @@ int x264_venc_encode_resident_loop(x264_t *h, const void *d_frames, uint64_t fra
     if (r < 0) {
         /* frames still inside belong to the failed call: drop them, so that n_in == n_out holds for the next call */
         (void)venc_sync(h->ctx);
-        h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
+        reset_counters(h);
     }
     return r;
 }
 
 static int resident_loop(x264_t *h, int n_frames, int64_t first_pts, x264_venc_sink sink, void *user) {
     /* frame numbering restarts so that resident frame f is input slot f */
-    h->n_in = h->n_out = h->n_launched = h->n_asm = 0;
+    reset_counters(h);
+    if (h->w_err) return -1;
     int delivered = 0, f = 0;
     x264_nal_t *nals;
     int nn;
@@ -456,11 +573,18 @@ static int resident_loop(x264_t *h, int n_frames, int64_t first_pts, x264_venc_s
         if (f >= n_frames && launch_pending(h, 1) != 0) return -1;
         t_launch += now_ms() - ta;
         ta = now_ms();
-        /* package the oldest unit while the GPU works on the next one, then hand it over in display order */
-        if (assemble_next_unit(h) != 0) return -1;
+        /* package the oldest unit while the GPU works on the next one (the packaging thread does, when there is one), then
+         * hand it over in display order */
+        int64_t upto;
+        if (h->worker_on) {
+            upto = h->n_out + h->unit < h->n_launched ? h->n_out + h->unit : h->n_launched;
+        } else {
+            if (assemble_next_unit(h) != 0) return -1;
+            upto = h->n_asm;
+        }
         t_asm += now_ms() - ta;
         ta = now_ms();
-        while (h->n_out < h->n_asm) {
+        while (h->n_out < upto) {
             const int bytes = deliver(h, &nals, &nn, &po);
             if (bytes < 0) return -1;
             if (sink && sink(user, nals, nn, bytes, &po) != 0) return -1;
