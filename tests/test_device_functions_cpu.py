@@ -181,3 +181,39 @@ def test_synth_source_is_deterministic_and_in_range(hc, venc):
     y3, _, _ = venc.synth_frame(w, h, 6, 0x1234ABCD)
     assert not np.array_equal(y, y3)
     assert 8 <= y.min() and y.max() <= 245
+
+
+def test_zero_block_test_is_exactly_the_quantiser(hc, orc):
+    """The transform kernels skip quantisation, dequantisation and the inverse transform of a wave whose blocks all pass
+    blk_all_zero (venc_inter2.hip); restated for the host as hc_block_all_zero.  It must hold exactly when every level is
+    zero under the ORACLE's inter quantiser -- on both sides of every threshold, every QP, every coefficient class."""
+    L = orc.lib()
+    hc.hc_block_all_zero.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    rng = np.random.default_rng(3)
+    for qp in range(12, 52):
+        # the largest |w| that still quantises to zero, per class (positions 0, 5, 1), found with the oracle's quantiser
+        edge = {}
+        for r in (0, 5, 1):
+            t = 0
+            while L.orc_quant(t + 1, qp, r, 0) == 0:
+                t += 1
+            edge[r] = t
+            assert L.orc_quant(-t, qp, r, 0) == 0 and L.orc_quant(-(t + 1), qp, r, 0) != 0
+        cls_of = [0, 2, 0, 2, 2, 1, 2, 1, 0, 2, 0, 2, 2, 1, 2, 1]
+        rep = {0: 0, 1: 5, 2: 1}
+        for first in (0, 1):
+            for trial in range(60):
+                w = np.zeros(16, np.int32)
+                for r in range(16):
+                    e = edge[rep[cls_of[r]]]
+                    w[r] = rng.integers(-e, e + 1)              # every coefficient inside its dead zone
+                assert hc.hc_block_all_zero(w.ctypes.data, qp, first) == 1
+                r = int(rng.integers(first, 16))
+                e = edge[rep[cls_of[r]]]
+                w[r] = (e + 1) * (1 if trial & 1 else -1)       # one coefficient just outside
+                assert hc.hc_block_all_zero(w.ctypes.data, qp, first) == 0
+                assert L.orc_quant(int(w[r]), qp, r, 0) != 0
+            if first == 1:                                      # a large DC is ignored when the DC is coded separately
+                w = np.zeros(16, np.int32)
+                w[0] = 9000
+                assert hc.hc_block_all_zero(w.ctypes.data, qp, 1) == 1 and hc.hc_block_all_zero(w.ctypes.data, qp, 0) == 0

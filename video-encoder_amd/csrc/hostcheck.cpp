@@ -20,6 +20,20 @@ void hc_fill_qparams(venc_qparams *q, int qp) {
     }
     q->f_intra = (1 << q->qbits) / 3;
     q->f_inter = (1 << q->qbits) / 6;
+    for (int k = 0; k < 3; k++) q->zt_inter[k] = ((1 << q->qbits) - q->f_inter - 1) / q->mf[k];
+}
+/* the zero-block test of the transform kernels (venc_inter2.hip blk_all_zero) restated for the host: 1 iff every
+ * coefficient from index `first` on quantises to level 0 */
+int hc_block_all_zero(const int *w, int qp, int first) {
+    venc_qparams q;
+    hc_fill_qparams(&q, qp);
+    unsigned m[3] = {0, 0, 0};
+    for (int r = first; r < 16; r++) {
+        const int cls = venc_pos_class(r);
+        const unsigned u = (unsigned)(w[r] + q.zt_inter[cls]);
+        if (u > m[cls]) m[cls] = u;
+    }
+    return m[0] <= 2u * (unsigned)q.zt_inter[0] && m[1] <= 2u * (unsigned)q.zt_inter[1] && m[2] <= 2u * (unsigned)q.zt_inter[2];
 }
 int hc_chroma_qp(int qp) { return qp < 30 ? qp : venc_qpc_hi[qp - 30]; }
 

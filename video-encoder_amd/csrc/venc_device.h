@@ -42,6 +42,7 @@ typedef struct {
     int mf[3]; /* MF[qp%6][class] */
     int v[3];  /* V[qp%6][class] */
     int f_intra, f_inter;
+    int zt_inter[3]; /* per class: the largest |w| that quantises to level 0 with the inter offset: (|w| mf + f_inter) >> qbits == 0 */
 } venc_qparams;
 
 /* zig-zag scan index -> raster index as a foldable expression (keeps unrolled

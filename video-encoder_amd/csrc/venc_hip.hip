@@ -166,6 +166,7 @@ static void fill_qparams(venc_qparams *q, int qp) {
     }
     q->f_intra = (1 << q->qbits) / 3;
     q->f_inter = (1 << q->qbits) / 6;
+    for (int k = 0; k < 3; k++) q->zt_inter[k] = ((1 << q->qbits) - q->f_inter - 1) / q->mf[k];
 }
 
 static int entropy_flush(venc_ctx *c);

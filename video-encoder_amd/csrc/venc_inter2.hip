@@ -68,6 +68,26 @@ DEVFN void blk_quant_res(const int w[16], const venc_qparams &q, int f, int d0, 
     if (DC_SEP) d[0] = d0;
     venc_idct4(d, rr);
 }
+/* ZERO BLOCKS.  Most 4x4 blocks of a P picture quantise to nothing (a macroblock of the 1080p clip averages 0.2 residual
+ * syntax units), and for those everything after the forward transform -- 16 quantisations, dequantisations, the inverse
+ * transform, 16 clips: ~280 of the ~450 instructions of a block -- reproduces the prediction.  The test is exact, not a
+ * SAD heuristic: level(w) = 0 <=> |w| <= zt[class] (the quantiser's own arithmetic, venc_qparams.zt_inter), i.e.
+ * (unsigned)(w + zt) <= 2 zt; one add per coefficient, a running maximum per class.  A wave whose blocks are all zero takes
+ * the short path (the decision must be wave-uniform to save anything). */
+template <bool DC_SEP>
+DEVFN bool blk_all_zero(const int w[16], const venc_qparams &q) {
+    uint32_t m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+    for (int r = DC_SEP ? 1 : 0; r < 16; r++) {
+        const int cls = venc_pos_class(r);
+        const uint32_t u = (uint32_t)(w[r] + (cls == 0 ? q.zt_inter[0] : cls == 1 ? q.zt_inter[1] : q.zt_inter[2]));
+        if (cls == 0) m0 = max(m0, u);
+        if (cls == 1) m1 = max(m1, u);
+        if (cls == 2) m2 = max(m2, u);
+    }
+    return m0 <= 2u * (uint32_t)q.zt_inter[0] && m1 <= 2u * (uint32_t)q.zt_inter[1] && m2 <= 2u * (uint32_t)q.zt_inter[2];
+}
+
 /* four rows of a current 4x4 block as packed dwords (aligned loads inside the display area, clamped bytes on its edges) */
 DEVFN void load_cur4x4_pk(const uint8_t *cur, int cstride, int pw, int ph, int px, int py, bool aligned, uint32_t cq[4]) {
     if (aligned && px + 4 <= pw && py + 4 <= ph) {
@@ -122,6 +142,20 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
         res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
     }
     venc_fdct4(res, w);
+    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+    if (__ballot(valid && !blk_all_zero<false>(w, g.ql)) == 0ull) {
+        /* every block of the wave quantises to zero: no levels, the reconstruction is the prediction */
+        if (valid) {
+            info->nnz[blk_y(blk) * 4 + blk_x(blk)] = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++) *(uint32_t *)(rec + (size_t)(py + y) * wstride + px) = pq[y];
+            if (blk == 0) {
+                info->cbp = 0;
+                info->flags = 0;
+            }
+        }
+        return;
+    }
     blk_quant_res<false>(w, g.ql, g.ql.f_inter, 0, lv, rr, nnz);
 #pragma unroll
     for (int y = 0; y < 4; y++) {
@@ -132,7 +166,6 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
     }
 
     int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
-    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
     const unsigned long long bal = __ballot(nnz > 0);
     if (valid) {
         if (nnz) store_levels(lv_mb + blk * 16, lv);
@@ -148,6 +181,35 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
             info->flags = 0;
         }
     }
+}
+
+/* One luma 4x4 block, no cross-lane traffic: residual, transform, quantisation, reconstruction; stores the levels, the
+ * block's TotalCoeff and the reconstructed samples.  For the blocks k_me_pool's P5 lists as not all-zero. */
+DEVFN void luma_block_full(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int mb, int blk, const uint32_t cq[4], const uint32_t pq[4]) {
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
+    int wstride;
+    uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
+    int res[16], w[16], lv[16], rr[16], nnz;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        res[4 * y] = byte_sub_byte<0>(cq[y], pq[y]);
+        res[4 * y + 1] = byte_sub_byte<1>(cq[y], pq[y]);
+        res[4 * y + 2] = byte_sub_byte<2>(cq[y], pq[y]);
+        res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
+    }
+    venc_fdct4(res, w);
+    blk_quant_res<false>(w, g.ql, g.ql.f_inter, 0, lv, rr, nnz);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        rr[4 * y] = venc_clip_u8(int_add_byte<0>(rr[4 * y], pq[y]));
+        rr[4 * y + 1] = venc_clip_u8(int_add_byte<1>(rr[4 * y + 1], pq[y]));
+        rr[4 * y + 2] = venc_clip_u8(int_add_byte<2>(rr[4 * y + 2], pq[y]));
+        rr[4 * y + 3] = venc_clip_u8(int_add_byte<3>(rr[4 * y + 3], pq[y]));
+    }
+    store_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + blk * 16, lv);
+    (B.mbinfo + (size_t)item * g.nmb + mb)->nnz[blk_y(blk) * 4 + blk_x(blk)] = (uint8_t)nnz;
+    store_rec4x4(rec, wstride, px, py, rr);
 }
 
 /* luma transform of macroblock mb with vector (dx, dy), current and predicted samples fetched from memory */
@@ -263,9 +325,18 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
         const int v = __shfl(dclv, qbase | qi);
         fc += (__popc(k & qi) & 1) ? -v : v;
     }
-    blk_quant_res<true>(w, g.qc, g.qc.f_inter, venc_dequant_chroma_dc(fc, &g.qc), lv, rr, nnz);
+    const int d0 = venc_dequant_chroma_dc(fc, &g.qc);
+    if (__ballot(valid && !blk_all_zero<true>(w, g.qc)) == 0ull) {
+        /* no AC level in any block of the wave: the inverse transform of a lone DC is (d0 + 32) >> 6 in every sample */
+        const int r0 = (d0 + 32) >> 6;
+        nnz = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) rr[i] = venc_clip_u8(p[i] + rr[i]);
+        for (int i = 0; i < 16; i++) lv[i] = 0, rr[i] = venc_clip_u8(p[i] + r0);
+    } else {
+        blk_quant_res<true>(w, g.qc, g.qc.f_inter, d0, lv, rr, nnz);
+#pragma unroll
+        for (int i = 0; i < 16; i++) rr[i] = venc_clip_u8(p[i] + rr[i]);
+    }
 
     int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;

@@ -38,7 +38,10 @@
 
 #define T3_POOL 1024 /* survivor pool of a tile = 8 wave segments of 2 x T3_CAP; entry = (LB << 15) | (macroblock << 11) | candidate */
 #define T3_CAP SEA_LIST /* survivors one macroblock may put into the pool (64); more: exhaustive search by k_me_fix */
-#define T3_CW 32                             /* current tile row stride in dwords: 128 pixels */
+#define T3_CW 36 /* current tile row stride in dwords: 128 pixels + 16 bytes.  A SAD's 16 lanes read 16 bytes each of 16 consecutive rows
+                    (ds_read_b128, banks of 64 dwords): at a stride of 32 dwords rows r and r + 2 share their banks -- an 8-way conflict,
+                    28 extra LDS cycles per read, the 5.7 M conflict cycles per launch of the round-1 counters; at 36 the 16 rows
+                    start at 16 different multiples of four banks */
 
 /* window piece i (row i / 10, columns 16 * (i % 10) ...): 16 bytes from the clamped address; a piece outside the
  * picture is replaced by the edge byte */
