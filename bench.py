@@ -171,11 +171,20 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     torch.cuda.synchronize()
 
     band_kw, xc, dmod = {}, None, None
+    c_exchange = slices_mode and args.backend == "nccl"
     if slices_mode:
         dmod = importlib.import_module("video-encoder_amd.dist")
         s0, cnt = dmod.slice_band(wl["slices"], world, rank)
-        xc = dmod.BandExchange(dmod.EnginePort(local_rank), wl["slices"], world, rank, halo_rows=args.halo)
-        band_kw = dict(slice_first=s0, slice_count=cnt, exchange=xc)
+        if c_exchange:
+            # the exchange runs inside the engine, in C on RCCL (include/venc_hip.h "RCCL exchange"): Python only carries
+            # rank 0's 128-byte communicator id to the peers, once
+            ident = [venc.rccl_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ident, src=0)
+            band_kw = dict(rccl=(world, rank, ident[0], args.halo))
+        else:  # gloo rehearsals: host-staged exchange through torch.distributed
+            xc = dmod.BandExchange(dmod.EnginePort(local_rank), wl["slices"], world, rank, halo_rows=args.halo)
+            band_kw = dict(slice_first=s0, slice_count=cnt, exchange=xc)
     enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
                            gop_batch=gop_batch, device=local_rank, **band_kw)
     if not args.no_profile:
@@ -195,11 +204,11 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     def one_pass():
         """streams: C tally sink.  slices: collect this band's payloads, gather them on rank 0 and
         interleave them into the whole-picture bitstream (part of the job, so inside the timing)."""
-        if not slices_mode:
+        if not slices_mode or world == 1:
             return enc.encode_resident_tally(clip.data_ptr(), fb, frames)
         mine = []
         enc.encode_resident(clip.data_ptr(), fb, frames, sink=lambda payload, nals, pts, key: mine.append(payload))
-        parts = dmod.gather_frames(mine)
+        parts = dmod.gather_frames_to_root(mine)  # rank 0 only: the bitstream is assembled where it is written out
         if rank == 0:
             whole = dmod.interleave_bands(parts)
             stream_info["frames"] = whole
@@ -209,7 +218,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     # (x264_venc_encode_resident_loop): the GPU works on pass k + 1 while the host packages pass k and hands it to the
     # sink, as a server encoding batch after batch does; --serial-steps makes K separate calls, each of which returns only
     # after its last frame was delivered.  slices mode: separate calls (the exchange callback is per call).
-    pipelined = not slices_mode and not args.serial_steps and steps > 1
+    pipelined = (not slices_mode or world == 1) and not args.serial_steps and steps > 1
     tally = None
     if pipelined and warmup > 0:
         # the warm-up goes through the same call; at least two passes, so that both halves of the engine's
@@ -246,7 +255,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     # chain's kernels takes longer although it does the same work).
     prof_iso, prof_all = {}, {}
     if not args.no_profile and rank == 0:
-        if not slices_mode:  # (every rank would have to join the exchanges of an extra pass)
+        if not slices_mode or world == 1:  # (every rank would have to join the exchanges of an extra pass)
             enc.profile_select(None, stride=1)
             enc.encode_resident_tally(clip.data_ptr(), fb, frames)
             prof_all, _ = enc.profile_read()
@@ -285,11 +294,15 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
         if digest:
             res["hip_sha256"], res["hip_sha256_frames"], res["hip_sha256_bytes"] = digest[0], want_digest_frames, digest[1]
         if slices_mode:
-            whole = stream_info.get("frames", [])
-            res["config"]["bytes_per_step"] = sum(len(f) for f in whole)
-            res["config"]["bitstream_sha256"] = hashlib.sha256(b"".join(whole)).hexdigest()
-            res["config"]["exchanges_per_step"] = xc.exchanges // max(1, steps + warmup)
-            res["config"].pop("bitstream_fnv1a", None)
+            eng = enc.L.x264_venc_engine(enc.h)
+            res["config"]["exchange"] = "C, RCCL (venc_band_exchange_rccl)" if c_exchange else "Python, torch.distributed %s (rehearsal)" % args.backend
+            n_x = venc.hip_lib().venc_rccl_exchanges(eng) if c_exchange else xc.exchanges
+            res["config"]["exchanges_per_step"] = int(n_x) // max(1, steps + warmup)
+            if world > 1:
+                whole = stream_info.get("frames", [])
+                res["config"]["bytes_per_step"] = sum(len(f) for f in whole)
+                res["config"]["bitstream_sha256"] = hashlib.sha256(b"".join(whole)).hexdigest()
+                res["config"].pop("bitstream_fnv1a", None)
         if prof:
             me_ms, me_n = prof.get("k_me", (0.0, 0))
             if me_n:

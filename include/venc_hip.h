@@ -123,6 +123,30 @@ int venc_band_import(venc_ctx *c, int n_items, const void *d_chunk, size_t item_
                      int halo_rows);
 void *venc_stream_handle(venc_ctx *c); /* hipStream_t of the main kernel chain */
 
+/* ---- RCCL exchange: the three steps above as ONE call, in C, on RCCL over xGMI (csrc/venc_rccl.hip) ----
+ * One communicator per context.  One process per GPU: rank 0 calls venc_rccl_unique_id, any out-of-band channel carries
+ * the 128 bytes to the peers, every rank calls venc_rccl_init_rank(ctx, id, world, rank).  One process driving all GPUs
+ * (a C host shaped like the reference, av_encode.c:840): venc_rccl_init_all(ctxs, n) = ncclCommInitAll.  Both set the
+ * context's band: the n_slices slices are dealt to the ranks in contiguous runs, earlier ranks take the remainder.
+ * venc_band_exchange_rccl(ctx, n_items, halo_rows) is then called after every step that a P picture follows:
+ * halo_rows = 16 sends the band's two 16-row halos to the two neighbours (grouped ncclSend / ncclRecv), halo_rows = 0
+ * all-gathers whole bands; everything is enqueued on the main stream, nothing blocks.  A single process calls it for each
+ * of its contexts between venc_rccl_group_begin() and venc_rccl_group_end().  venc_rccl_agree(ctx, flag) is a
+ * host-synchronous MAX of `flag` over the ranks (use it at the end of a pass: a rank that failed makes all ranks stop).
+ * RCCL is loaded at run time (librccl.so.1; VENC_RCCL_LIB overrides): engines that never call these do not load it. */
+#define VENC_RCCL_ID_BYTES 128
+int venc_rccl_unique_id(uint8_t id[VENC_RCCL_ID_BYTES]);
+int venc_rccl_init_rank(venc_ctx *c, const uint8_t id[VENC_RCCL_ID_BYTES], int world, int rank);
+int venc_rccl_init_all(venc_ctx **ctxs, int n);
+int venc_rccl_world(const venc_ctx *c);
+int venc_rccl_rank(const venc_ctx *c);
+int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows);
+int venc_rccl_group_begin(void);
+int venc_rccl_group_end(void);
+int venc_rccl_agree(venc_ctx *c, int local_flag);
+long long venc_rccl_exchanges(const venc_ctx *c);
+void venc_rccl_always(venc_ctx *c, int on); /* tests: run the collective even in a world of one */
+
 /* Completion tracking: venc_mark() returns a ticket for everything issued so
  * far; venc_wait(ticket) blocks the host until that point.  The engine may defer
  * the entropy chain of up to four consecutive P steps and launch it once for all

@@ -98,6 +98,14 @@ typedef struct x264_param_t {
         int i_slice_first, i_slice_count;
         int (*pf_exchange)(void *user, void *engine, int n_items);
         void *p_exchange_user;
+        /* The same exchange done by the engine itself over RCCL (include/venc_hip.h, "RCCL exchange"), for C hosts:
+         * i_rccl_world > 0 makes x264_encoder_open join a communicator of that many ranks as rank i_rccl_rank with
+         * the 128-byte id rank 0 obtained from venc_rccl_unique_id(); the band follows from world and rank (slices
+         * dealt in contiguous runs; i_slice_first / i_slice_count are ignored) and every exchange is one call on the
+         * engine's stream: i_halo_rows = 16 (neighbours' halos, grouped ncclSend / ncclRecv) or 0 (whole bands,
+         * ncclAllGather).  pf_exchange, when set, takes precedence. */
+        int i_rccl_world, i_rccl_rank, i_halo_rows;
+        unsigned char rccl_id[128];
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;

@@ -180,3 +180,46 @@ def test_two_rank_gloo_band_encoders_reproduce_the_single_stream(halo_rows, gop_
         assert p.exitcode == 0
     assert n == 10 and same_single and same_oracle
     assert exchanges > 0
+
+
+@pytest.mark.parametrize("halo_rows,gop_batch", [(16, 1), (0, 1), (16, 3)])
+def test_c_level_rccl_exchange_world_of_one(venc, halo_rows, gop_batch):
+    """The exchange done by the engine itself, in C on RCCL (include/venc_hip.h "RCCL exchange": venc_rccl_unique_id,
+    venc_rccl_init_rank, venc_band_exchange_rccl -- librccl bound at run time), through the x264 API's hip.i_rccl_*
+    parameters; no Python on the per-picture path.  One rank is all a one-GPU box can host (RCCL refuses two ranks on
+    one device), so the collective runs with itself as its only member: pack kernel, grouped send / receive (halo) or
+    all-gather (whole band) on the engine's stream, unpack loop.  Stream identical to the plain encoder's; the exchange
+    count is one per picture that a P picture follows; venc_rccl_agree returns the maximum flag."""
+    H = venc.hip_lib()
+    w, h, n, keyint = 352, 288, 8, 4
+    frames = [venc.synth_frame(w, h, t) for t in range(n)]
+    kw = dict(qp=26, slices=4, keyint=keyint, gop_batch=gop_batch)
+    if gop_batch == 1:
+        kw["tune"] = "zerolatency"
+    e = venc.X264Encoder(w, h, rccl=(1, 0, venc.rccl_unique_id(), halo_rows), **kw)
+    eng = e.L.x264_venc_engine(e.h)
+    assert H.venc_rccl_world(eng) == 1 and H.venc_rccl_rank(eng) == 0
+    H.venc_rccl_always(eng, 1)
+    got = []
+    for t, (y, u, v) in enumerate(frames):
+        r = e.encode(y, u, v, t)
+        if r is not None:
+            got.append(r.payload)
+    got += [r.payload for r in e.flush()]
+    units = n // keyint if gop_batch == 1 else 1  # GOPs in lock-step share their exchanges: one per step
+    assert H.venc_rccl_exchanges(eng) == units * (keyint - 1)
+    assert H.venc_rccl_agree(eng, 0) == 0 and H.venc_rccl_agree(eng, 5) == 5
+    e.close()
+    assert got == _stream(venc, frames, w, h, **kw)
+
+
+def test_c_level_rccl_arguments_are_checked(venc):
+    H = venc.hip_lib()
+    e = venc.Engine(176, 144, qp=30, n_slices=3, max_items=1, in_slots=2, out_slots=2)
+    assert H.venc_band_exchange_rccl(e.h, 1, 16) != 0          # no communicator yet
+    ident = venc.rccl_unique_id()
+    import ctypes as C
+    buf = (C.c_ubyte * 128).from_buffer_copy(ident)
+    assert H.venc_rccl_init_rank(e.h, buf, 4, 0) != 0          # more ranks than slices: refused before RCCL is called
+    assert b"slices" in H.venc_last_error()
+    e.close()

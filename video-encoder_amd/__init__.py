@@ -79,7 +79,8 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int)
 class _Hip(C.Structure):
     _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int),
                 ("i_slice_first", C.c_int), ("i_slice_count", C.c_int), ("pf_exchange", EXCHANGE_FN),
-                ("p_exchange_user", C.c_void_p)]
+                ("p_exchange_user", C.c_void_p), ("i_rccl_world", C.c_int), ("i_rccl_rank", C.c_int),
+                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128)]
 
 
 class X264Param(C.Structure):
@@ -163,6 +164,17 @@ def bind_hip(L):
         L.venc_band_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
         L.venc_stream_handle.restype = C.c_void_p
         L.venc_stream_handle.argtypes = [C.c_void_p]
+        L.venc_rccl_unique_id.argtypes = [C.c_void_p]
+        L.venc_rccl_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.venc_rccl_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.venc_rccl_world.argtypes = [C.c_void_p]
+        L.venc_rccl_rank.argtypes = [C.c_void_p]
+        L.venc_band_exchange_rccl.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.venc_rccl_agree.argtypes = [C.c_void_p, C.c_int]
+        L.venc_rccl_exchanges.restype = C.c_longlong
+        L.venc_rccl_exchanges.argtypes = [C.c_void_p]
+        L.venc_rccl_always.restype = None
+        L.venc_rccl_always.argtypes = [C.c_void_p, C.c_int]
     return L
 
 
@@ -299,6 +311,14 @@ class FrameSource:
 
     def __del__(self):
         self.close()
+
+
+def rccl_unique_id():
+    """128-byte RCCL id (rank 0 calls this and hands the bytes to its peers: venc_rccl_unique_id)."""
+    buf = (C.c_ubyte * 128)()
+    if hip_lib().venc_rccl_unique_id(buf) != 0:
+        raise VencError("venc_rccl_unique_id failed: %s" % hip_lib().venc_last_error().decode())
+    return bytes(buf)
 
 
 def synth_frame(width, height, frame_index, seed=0x1234ABCD):
@@ -448,9 +468,11 @@ class X264Encoder:
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
                  tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0,
-                 slice_first=0, slice_count=0, exchange=None):
+                 slice_first=0, slice_count=0, exchange=None, rccl=None):
         """slice_first / slice_count / exchange: slice-parallel multi-GPU mode (include/x264.h, hip extension);
-        exchange(engine_view, n_items) is called after every picture that a P picture follows."""
+        exchange(engine_view, n_items) is called after every picture that a P picture follows.
+        rccl = (world, rank, id_bytes, halo_rows): the engine does the exchange itself in C over RCCL
+        (include/venc_hip.h "RCCL exchange"); the band follows from world and rank."""
         self.L = x264_lib()
         p = X264Param()
         if self.L.x264_param_default_preset(C.byref(p), preset.encode() if preset else None,
@@ -467,6 +489,10 @@ class X264Encoder:
         p.i_keyint_max, p.i_slice_count = keyint, slices
         p.hip.i_device, p.hip.i_gop_batch, p.hip.i_gop_base = device, gop_batch, gop_base
         p.hip.i_slice_first, p.hip.i_slice_count = slice_first, slice_count
+        if rccl is not None:
+            world, rank, ident, halo = rccl
+            p.hip.i_rccl_world, p.hip.i_rccl_rank, p.hip.i_halo_rows = world, rank, halo
+            C.memmove(p.hip.rccl_id, bytes(ident), 128)
         self._exchange_error = None
         if exchange is not None:
             def _xc(user, engine_ptr, n_items):

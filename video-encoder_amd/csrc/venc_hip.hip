@@ -10,6 +10,7 @@
  * consumes (av_encode.c:670-834).
  */
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> /* types only: the library is bound at run time (venc_rccl.hip) */
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -123,6 +124,13 @@ struct venc_ctx {
     int me_mode;  /* 0 pool (default): k_me_pool, successive elimination with in-kernel sums, pooled survivors, three
                      blocks per CU; 3 tile: its predecessor k_me_tile; 1 plane: sums from k_refsum; 2 dense: exhaustive
                      search.  Env VENC_ME=pool|tile|plane|dense (VENC_ME_DENSE=1 = dense). */
+    /* slice-parallel mode over RCCL (venc_rccl.hip) */
+    ncclComm_t rc_comm;
+    int rc_world, rc_rank, rc_items, rc_halo, rc_always;
+    void *rc_send, *rc_recv; /* own chunk; one chunk per rank (all-gather layout) */
+    size_t rc_item_stride;
+    int *rc_flag;
+    long long rc_exchanges;
     /* optional per-kernel HIP-event timing (venc_profile) */
     int prof_on;
     int prof_stride, prof_seen[16]; /* event pairs around every prof_stride-th launch of a selected kernel */
@@ -186,11 +194,14 @@ extern "C" int venc_device_count(void) {
     return n;
 }
 
+static void rccl_release(venc_ctx *c);
+
 extern "C" void venc_close(venc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream && c->stream2 && c->b.mbbits) (void)entropy_flush(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    rccl_release(c);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     if (c->ev)
@@ -1243,3 +1254,5 @@ extern "C" int venc_synth_device(void *d_frames, size_t frame_stride, int width,
     HIP_OK(hipDeviceSynchronize());
     return 0;
 }
+
+#include "venc_rccl.hip"

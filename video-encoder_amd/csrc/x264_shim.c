@@ -65,6 +65,7 @@ struct x264_t {
     double trace_t0;    /* VENC_TRACE: start of the resident call (0 = no trace) */
     int64_t ext_clip;   /* resident mode: frames in the resident clip; stream frame f reads clip frame f % ext_clip */
     int band_first, band_count; /* slices coded by this encoder (slice-parallel mode), 0/0 = all */
+    int rccl;                   /* the engine exchanges bands itself over RCCL (hip.i_rccl_world > 0) */
     /* gop_batch > 1: NAL packaging (the wait for the GPU, emulation prevention, length prefixes: ~1.9 ms per 300-frame
      * 1080p unit) runs on a thread of its own, in the order the GPU completes frames, beside the caller's thread, which
      * launches units and hands frames to the sink in display order.  The reference's caller stays single-threaded: it
@@ -80,8 +81,9 @@ struct x264_t {
 /* slice-parallel mode: let the bands' owners swap reconstructed rows before the next P picture */
 static int exchange_after_step(x264_t *h, int n_items) {
     if (!h->band_count) return 0;
-    if (!h->param.hip.pf_exchange) return 0; /* a single band covering every slice needs no peer */
-    return h->param.hip.pf_exchange(h->param.hip.p_exchange_user, h->ctx, n_items) != 0 ? -1 : 0;
+    if (h->param.hip.pf_exchange) return h->param.hip.pf_exchange(h->param.hip.p_exchange_user, h->ctx, n_items) != 0 ? -1 : 0;
+    if (h->rccl) return venc_band_exchange_rccl(h->ctx, n_items, h->param.hip.i_halo_rows) != 0 ? -1 : 0;
+    return 0; /* a single band covering every slice needs no peer */
 }
 
 static double now_ms(void) {
@@ -214,7 +216,18 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     h->seq.sar_w = param->vui.i_sar_width;
     h->seq.sar_h = param->vui.i_sar_height;
     h->nal_cap = 2 + venc_n_slices(h->ctx);
-    if (param->hip.i_slice_count > 0 || param->hip.i_slice_first > 0) {
+    if (param->hip.i_rccl_world > 0 && !param->hip.pf_exchange) {
+        /* C-level slice-parallel mode: the engine joins the communicator and takes the band of its rank */
+        const int ns = venc_n_slices(h->ctx), world = param->hip.i_rccl_world, rank = param->hip.i_rccl_rank;
+        if (venc_rccl_init_rank(h->ctx, param->hip.rccl_id, world, rank) != 0) {
+            fprintf(stderr, "x264 [venc]: %s\n", venc_last_error());
+            x264_encoder_close(h);
+            return NULL;
+        }
+        h->rccl = 1;
+        h->band_first = rank * (ns / world) + (rank < ns % world ? rank : ns % world);
+        h->band_count = ns / world + (rank < ns % world ? 1 : 0);
+    } else if (param->hip.i_slice_count > 0 || param->hip.i_slice_first > 0) {
         const int ns = venc_n_slices(h->ctx);
         h->band_first = param->hip.i_slice_first;
         h->band_count = param->hip.i_slice_count > 0 ? param->hip.i_slice_count : ns - param->hip.i_slice_first;

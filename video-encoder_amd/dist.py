@@ -181,6 +181,18 @@ def interleave_bands(per_rank_frames):
     return [b"".join(p[f] for p in per_rank_frames) for f in range(n)]
 
 
+def gather_frames_to_root(frames, group=None, root=0):
+    """Every rank's per-frame payload list on `root` only (None elsewhere): the bitstream is assembled where it is
+    written out, the other ranks receive nothing."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [list(frames)]
+    me = dist.get_rank(group)
+    parts = [None] * dist.get_world_size(group) if me == root else None
+    dist.gather_object([bytes(f) for f in frames], parts, dst=root, group=group)
+    return parts
+
+
 def gather_frames(frames, group=None):
     """All ranks' per-frame payload lists on rank 0 (control plane: bitstream bytes, not pixels)."""
     import torch.distributed as dist
