@@ -33,6 +33,9 @@ int venc_source_height(const venc_source *s);
 /* frame rate and pixel aspect ratio (30:1 and 1:1 when the file does not say) */
 void venc_source_rate(const venc_source *s, int *fps_num, int *fps_den);
 void venc_source_aspect(const venc_source *s, int *sar_num, int *sar_den);
+/* frames in the file, from its size (the reference takes the duration of its progress line from the container,
+ * av_encode.c:1032-1069); -1 when the size is unknown (a pipe) */
+long venc_source_frame_count(const venc_source *s);
 /* 1: a frame was read into pic's planes; 0: end of stream; < 0: truncated or malformed input */
 int venc_source_read(venc_source *s, x264_picture_t *pic);
 

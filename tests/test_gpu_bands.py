@@ -223,3 +223,31 @@ def test_c_level_rccl_arguments_are_checked(venc):
     assert H.venc_rccl_init_rank(e.h, buf, 4, 0) != 0          # more ranks than slices: refused before RCCL is called
     assert b"slices" in H.venc_last_error()
     e.close()
+
+
+def test_c_level_rccl_single_process_init_all(venc, orc):
+    """A C host that drives every GPU from one process (the reference's shape: one program, one thread) uses
+    venc_rccl_init_all (= ncclCommInitAll over the contexts' devices) and brackets the per-context exchanges of a picture
+    with venc_rccl_group_begin / venc_rccl_group_end.  On the one-GPU box: one context, which then codes the whole picture;
+    slices equal the oracle's."""
+    import ctypes as C
+    H = venc.hip_lib()
+    w, h, n = 352, 288, 4
+    e = venc.Engine(w, h, qp=28, n_slices=4, max_items=1, in_slots=2, out_slots=2)
+    arr = (C.c_void_p * 1)(e.h)
+    assert H.venc_rccl_init_all(arr, 1) == 0, H.venc_last_error()
+    assert H.venc_rccl_world(e.h) == 1 and e.band_rows(0, 4) == (0, 18)
+    H.venc_rccl_always(e.h, 1)
+    ref = orc.Encoder(w, h, qp=28, n_slices=4, keyint=n, threads=4)
+    for t in range(n):
+        f = venc.synth_frame(w, h, t, 3)
+        e.upload(t & 1, *f)
+        e.encode_step([t & 1], [t & 1], t == 0, t & 15, [0])
+        assert H.venc_rccl_group_begin() == 0
+        assert H.venc_band_exchange_rccl(e.h, 1, 16) == 0, H.venc_last_error()
+        assert H.venc_rccl_group_end() == 0
+        e.sync()
+        want = [unescape(b) for (ty, _, b) in split_nals(ref.encode(*f).data) if ty in (1, 5)]
+        assert e.get_slices(t & 1) == want, "frame %d" % t
+    assert H.venc_rccl_exchanges(e.h) == n
+    e.close()

@@ -501,3 +501,51 @@ def test_p_skip_runs_match_oracle(venc, orc, kind):
         assert 0.3 * nmb_p < skipped < 0.6 * nmb_p
     else:
         assert skipped > 0
+
+
+def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path):
+    """tools/av_encode: the reference's command line with its SHORT options (av_encode.c:127 "sdv:a:l:f:"), on a
+    terminal-like stdin (the reference's default for --silent is !isatty(stdin), av_encode.c:92), so the progress line
+    of av_encode.c:1032-1069 is printed (video half: position, percentage, time left).  --frame-limit is enforced; the
+    file's samples equal the oracle's slices."""
+    import os
+    import pty
+    import re
+    import subprocess
+    from test_io import read_track, samples_of, _write_y4m
+    w, h, n = 176, 144, 12
+    frames = [venc.synth_frame(w, h, t, 7) for t in range(n)]
+    y4m, mp4 = str(tmp_path / "in.y4m"), str(tmp_path / "out.mp4")
+    _write_y4m(y4m, frames, w, h, header_extra="F25:1 Ip A1:1 C420jpeg")
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "av_encode")
+    env = dict(os.environ, VENC_PROGRESS_INTERVAL="0", VENC_SLICES="3", VENC_KEYINT="5")
+
+    def run_on_terminal(args):
+        """stdin = a pseudo-terminal where the box has pty devices; else the driver's stand-in VENC_ASSUME_TTY"""
+        try:
+            master, slave = pty.openpty()
+        except OSError:
+            return subprocess.run(args, stdin=subprocess.DEVNULL, capture_output=True, text=True, env=dict(env, VENC_ASSUME_TTY="1"))
+        try:
+            return subprocess.run(args, stdin=slave, capture_output=True, text=True, env=env)
+        finally:
+            os.close(master)
+            os.close(slave)
+    r = run_on_terminal([tool, "-d", "-l", "9", "-v", "0", "--tune", "zerolatency", "--quality", "27.4", y4m, mp4])
+    assert r.returncode == 0, r.stderr
+    assert "silent: 0" in r.stdout and "frame_limit: 9" in r.stdout and "video_stream_index: 0" in r.stdout and "quality: 27.400000" in r.stdout
+    lines = re.findall(r"video: (\d+):(\d\d):(\d\d) \((\d+\.\d)%\) - time left: \d+:\d\d:\d\d", r.stdout)
+    assert len(lines) >= 8, r.stdout                       # one per frame at interval 0 (-d: each on its own line)
+    pct = [float(x[3]) for x in lines]
+    assert pct == sorted(pct) and pct[-1] <= 100.0 and pct[-1] > 50.0
+    t = read_track(open(mp4, "rb").read())
+    assert len(t["stsz"]) == 9 and t["stss"] == [1, 6] and t["timescale"] == 25
+    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4)
+    got = samples_of(open(mp4, "rb").read(), t)
+    for k in range(9):
+        ref = enc.encode(*frames[k])
+        first = min(off for (ty, _, off, _) in ref.nals if ty not in (7, 8))
+        assert got[k] == ref.data[first:], "sample %d" % k
+    # -s: silent, no progress line
+    r = run_on_terminal([tool, "-s", "-l", "3", y4m, mp4])
+    assert r.returncode == 0 and "video:" not in r.stdout and "silent: 1" in r.stdout

@@ -262,3 +262,32 @@ def test_sources_refuse_what_they_cannot_read(venc, tmp_path):
     open(p, "wb").write(bytes(384))
     with pytest.raises(venc.VencError):
         venc.FrameSource(p)
+
+
+def test_av_encode_command_line_errors_match_the_reference():
+    """tools/av_encode = the reference's command line (av_encode.c:89-196): getopt_long over "sdv:a:l:f:" and the four
+    long-only x264 options, then "input output".  A bad command line ends with the reference's messages and main's exit
+    code 1 before anything touches the GPU."""
+    import importlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "av_encode")
+    if not os.path.exists(tool):
+        importlib.import_module("video-encoder_amd").build()
+    r = subprocess.run([tool], capture_output=True, text=True)
+    assert r.returncode == 1 and "no input file specified!" in r.stderr
+    r = subprocess.run([tool, "-s", "-l", "7", "--preset", "fast", "in.y4m"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no output file specified!" in r.stderr
+    r = subprocess.run([tool, "-Z", "a", "b"], capture_output=True, text=True)
+    assert r.returncode == 1 and "invalid option" in r.stderr
+    r = subprocess.run([tool, "--frame-limit"], capture_output=True, text=True)
+    assert r.returncode == 1 and "requires an argument" in r.stderr
+    # a complete command line is echoed in the reference's format (av_encode.c:188-193) before the input is opened
+    r = subprocess.run([tool, "-d", "-v", "1", "-a", "2", "-l", "9", "-f", "yadif", "--quality", "23", "/nonexistent.y4m", "/tmp/x.mp4"],
+                       capture_output=True, text=True)
+    assert r.returncode == 2  # the source cannot be opened
+    for line in ("silent: 1", "debug: 1", "input_file: /nonexistent.y4m", "output_file: /tmp/x.mp4", "video_stream_index: 1",
+                 "audio_stream_index: 2", "frame_limit: 9", "video_filter: yadif", "preset: medium", "tune: film", "quality: 23.000000",
+                 "profile: (null)"):
+        assert line in r.stdout, line

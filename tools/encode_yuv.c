@@ -34,6 +34,14 @@
  * filters belong to the libav* stages that are out of scope: accepted and ignored with a note.  Unless
  * --silent (default when stdin is not a terminal, as in the reference) a progress line in the
  * reference's format is printed every half second (av_encode.c:1032-1069, without the audio half).
+ *
+ * Built a second time as tools/av_encode (-DAV_ENCODE_CLI): the reference's command line and nothing else, parsed exactly
+ * as av_encode.c:110-187 parses it -- getopt_long with the option string "sdv:a:l:f:", so the SHORT options work too
+ * (-s silent, -d debug, -v / -a stream indices, -l frame limit, -f filters), then "input output"; the option dump of
+ * av_encode.c:188-193, the exit codes of main (1: bad command line, ...), and the progress line.  The driver's own
+ * switches (-n -q -S -k -g -t -i -o -m) exist in encode_yuv only; in av_encode the stream constants they set keep the
+ * defaults of x264_param_default_preset (8 slices, GOP 30) and can be overridden through VENC_SLICES / VENC_KEYINT /
+ * VENC_GOP_BATCH in the environment.
  */
 #define _GNU_SOURCE
 #include <getopt.h>
@@ -213,9 +221,65 @@ int main(int argc, char **argv) {
     int w = 0, h = 0, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 1, fps = 30, fps_den = 1, sar_num = 1, sar_den = 1;
     int fps_given = 0;
     const char *in = NULL, *out = NULL, *mp4 = NULL, *tune = "film", *preset = "medium", *profile = NULL;
-    bool silent = !isatty(STDIN_FILENO), debug_show = false, ref_cli = false;
+    /* the reference's default (av_encode.c:92); VENC_ASSUME_TTY=1 stands in for a terminal where none can be had (test boxes without pty devices) */
+    bool silent = !isatty(STDIN_FILENO) && !getenv("VENC_ASSUME_TTY"), debug_show = false, ref_cli = false;
     long long frame_limit = -1;
     float quality = -1.0f;
+    int video_stream_index = -1, audio_stream_index = -1;
+    const char *video_filter = NULL;
+#ifdef AV_ENCODE_CLI
+    /* the reference's parse_cli_options (av_encode.c:89-196), option for option */
+    {
+        static const struct option long_opts[] = {{"silent", no_argument, NULL, 's'},          {"debug", no_argument, NULL, 'd'},
+                                                  {"video-stream", required_argument, NULL, 'v'}, {"audio-stream", required_argument, NULL, 'a'},
+                                                  {"frame-limit", required_argument, NULL, 'l'}, {"filters", required_argument, NULL, 'f'},
+                                                  {"preset", required_argument, NULL, 1},        {"tune", required_argument, NULL, 2},
+                                                  {"quality", required_argument, NULL, 3},       {"profile", required_argument, NULL, 4},
+                                                  {NULL, 0, NULL, 0}};
+        int idx = 0, opt;
+        quality = 20.0f; /* av_encode.c:104 */
+        while ((opt = getopt_long(argc, argv, "sdv:a:l:f:", long_opts, &idx)) != -1) {
+            switch (opt) {
+                case 's': silent = true; break;
+                case 'd': debug_show = true; break;
+                case 'v': video_stream_index = (int)strtol(optarg, NULL, 10); break;
+                case 'a': audio_stream_index = (int)strtol(optarg, NULL, 10); break;
+                case 'l': frame_limit = strtoll(optarg, NULL, 10); break;
+                case 'f': video_filter = optarg; break;
+                case 1: preset = optarg; break;
+                case 2: tune = optarg; break;
+                case 3: quality = strtof(optarg, NULL); break;
+                case 4: profile = optarg; break;
+                default: return 1; /* getopt_long has printed the message (av_encode.c:160-163, main's return 1) */
+            }
+        }
+        if (optind < argc)
+            in = argv[optind++];
+        else {
+            fprintf(stderr, "no input file specified!\n");
+            return 1;
+        }
+        if (optind < argc) {
+            const char *o = argv[optind++];
+            const size_t n = strlen(o);
+            if (n > 4 && !strcmp(o + n - 4, ".mp4")) mp4 = o; else out = o;
+        } else {
+            fprintf(stderr, "no output file specified!\n");
+            return 1;
+        }
+        printf("silent: %d \ndebug: %d \ninput_file: %s \noutput_file: %s \nvideo_stream_index: %d \naudio_stream_index: %d \nframe_limit: %ld \nvideo_filter: %s \npreset: %s \ntune: %s \nquality: %f \nprofile: %s\n",
+               silent, debug_show, in, mp4 ? mp4 : out, video_stream_index, audio_stream_index, (long)frame_limit, video_filter ? video_filter : "(null)", preset,
+               tune, (double)quality, profile ? profile : "(null)");
+        if (video_stream_index >= 0 || audio_stream_index >= 0 || video_filter)
+            fprintf(stderr, "note: stream selection and filters belong to the demux/decode/filter stages, which are out of scope: ignored\n");
+        if (getenv("VENC_SLICES")) slices = atoi(getenv("VENC_SLICES"));
+        if (getenv("VENC_KEYINT")) keyint = atoi(getenv("VENC_KEYINT"));
+        if (getenv("VENC_GOP_BATCH")) gop_batch = atoi(getenv("VENC_GOP_BATCH"));
+        frames = 0x7fffffff;
+        argc = 1; /* nothing left for the driver's own switches */
+    }
+#else
+    (void)video_stream_index, (void)audio_stream_index, (void)video_filter;
     /* first pass: the reference's long options (av_encode.c:110-124); they are removed from argv */
     {
         static const struct option long_opts[] = {{"silent", no_argument, NULL, 's'},          {"debug", no_argument, NULL, 'd'},
@@ -280,6 +344,7 @@ int main(int argc, char **argv) {
     }
     if (ref_cli && quality < 0) quality = 20.0f; /* av_encode.c:104 */
     if (ref_cli) frames = 0x7fffffff;             /* the whole input, or --frame-limit */
+#endif
     for (int i = 1; i < argc; i++) {
         const char *a = argv[i], *v = i + 1 < argc ? argv[i + 1] : NULL;
         if (!strcmp(a, "-s") && v && sscanf(v, "%dx%d", &w, &h) == 2) i++;
@@ -312,7 +377,11 @@ int main(int argc, char **argv) {
     }
     x264_context_t x264;
     memset(&x264, 0, sizeof(x264));
+#ifdef AV_ENCODE_CLI
+    if (quality >= 0) qp = (int)quality; /* the reference hands its float option to an int parameter (av_encode.c:79, :380, :895): truncated */
+#else
     if (quality >= 0) qp = (int)(quality + 0.5f);
+#endif
     if (frame_limit >= 0 && frame_limit < frames) frames = (int)frame_limit;
     if (ref_cli)
         printf("silent: %d \ndebug: %d \ninput_file: %s \noutput_file: %s \nframe_limit: %lld \npreset: %s \ntune: %s \nquality: %f \nprofile: %s\n", silent,
@@ -324,11 +393,20 @@ int main(int argc, char **argv) {
     const double t0 = now_s();
     double last_progress = t0;
     int64_t encoded_video_pts = 0;
+    /* progress line of av_encode.c:1032-1069, video half: position, percentage of the input's duration, estimated time
+     * left = (duration left / duration encoded) x time spent; every half second (VENC_PROGRESS_INTERVAL overrides: tests) */
+    const double progress_every = getenv("VENC_PROGRESS_INTERVAL") ? atof(getenv("VENC_PROGRESS_INTERVAL")) : 0.5;
+    long total_frames = src ? venc_source_frame_count(src) : frames;
+    if (total_frames > frames) total_frames = frames;
+    const double duration_sec = total_frames > 0 ? (double)total_frames * fps_den / fps : 0.0;
     for (int f = 0; f < frames; f++) {
-        if (!silent && now_s() - last_progress > 0.5) { /* av_encode.c:1032-1069, video half */
-            const double secs = (double)encoded_video_pts * fps_den / fps;
+        if (!silent && now_s() - last_progress > progress_every) {
+            const double secs = (double)encoded_video_pts * fps_den / fps, spent = now_s() - t0;
             const long long s = (long long)secs;
-            printf("\rvideo: %lld:%02lld:%02lld (frame %d) - %.1f frames/s", s / 3600, (s / 60) % 60, s % 60, f, f / (now_s() - t0));
+            const double left = secs > 0 && duration_sec > secs ? (duration_sec - secs) / secs * spent : 0.0;
+            const long long l = (long long)left;
+            printf("\rvideo: %lld:%02lld:%02lld (%.1lf%%) - time left: %lld:%02lld:%02lld", s / 3600, (s / 60) % 60, s % 60,
+                   duration_sec > 0 ? secs / duration_sec * 100 : 0.0, l / 3600, (l / 60) % 60, l % 60);
             if (debug_show) printf("\n"); else fflush(stdout);
             last_progress = now_s();
         }

@@ -132,11 +132,16 @@ static int rccl_buffers(venc_ctx *c, int n_items, int halo_rows) {
     return 0;
 }
 
-static int rccl_attach(venc_ctx *c, ncclComm_t comm, int world, int rank) {
+/* checked BEFORE a communicator is created: ncclCommInitRank blocks until all ranks of the world have called it */
+static int rccl_world_fits(const venc_ctx *c, int world) {
     if (world > c->g.n_slices) {
         SET_ERR("venc_rccl: %d ranks but only %d slices (the slice count is a stream constant, not the GPU count)", world, c->g.n_slices);
         return -1;
     }
+    return 0;
+}
+
+static int rccl_attach(venc_ctx *c, ncclComm_t comm, int world, int rank) {
     c->rc_comm = comm;
     c->rc_world = world;
     c->rc_rank = rank;
@@ -150,7 +155,7 @@ extern "C" int venc_rccl_init_rank(venc_ctx *c, const uint8_t id[VENC_RCCL_ID_BY
         SET_ERR("venc_rccl_init_rank: bad arguments (world %d, rank %d)", world, rank);
         return -1;
     }
-    if (rccl_load() != 0) return -1;
+    if (rccl_world_fits(c, world) != 0 || rccl_load() != 0) return -1;
     HIP_OK(hipSetDevice(c->cfg.device));
     ncclUniqueId u;
     memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
@@ -172,6 +177,7 @@ extern "C" int venc_rccl_init_all(venc_ctx **ctxs, int n) {
             SET_ERR("venc_rccl_init_all: context %d is null or already has a communicator", i);
             return -1;
         }
+        if (rccl_world_fits(ctxs[i], n) != 0) return -1;
         devs[i] = ctxs[i]->cfg.device;
     }
     NCCL_OK(g_nccl.CommInitAll(comms, n, devs));

@@ -15,6 +15,7 @@ struct venc_source {
     int width, height;
     int fps_num, fps_den, sar_num, sar_den;
     long frames_read;
+    long frame_count; /* from the file size, -1 if unknown */
 };
 
 static int parse_ratio(const char *s, int *a, int *b) {
@@ -89,6 +90,18 @@ venc_source *venc_source_open(const char *filename, int width, int height) {
         fprintf(stderr, "source: unsupported picture size %dx%d (both must be even)\n", s->width, s->height);
         goto fail;
     }
+    {
+        /* frames = payload bytes / (frame bytes + the 6 bytes of a plain "FRAME\n" line): exact for files written without
+         * per-frame parameters, an estimate otherwise (it only feeds a progress percentage) */
+        s->frame_count = -1;
+        const long here = ftell(s->f);
+        if (here >= 0 && fseek(s->f, 0, SEEK_END) == 0) {
+            const long end = ftell(s->f);
+            const long per = (long)s->width * s->height * 3 / 2 + (s->y4m ? 6 : 0);
+            if (end >= here && per > 0) s->frame_count = (end - here) / per;
+            if (fseek(s->f, here, SEEK_SET) != 0) goto fail;
+        }
+    }
     return s;
 fail:
     fclose(s->f);
@@ -101,6 +114,7 @@ void venc_source_close(venc_source *s) {
     fclose(s->f);
     free(s);
 }
+long venc_source_frame_count(const venc_source *s) { return s->frame_count; }
 int venc_source_width(const venc_source *s) { return s->width; }
 int venc_source_height(const venc_source *s) { return s->height; }
 void venc_source_rate(const venc_source *s, int *n, int *d) {
