@@ -57,6 +57,13 @@ static thread_local char g_err[512] = "";
  * main chain (round 1: 3.8 ms against 4.2 ms per 1080p pass).  A wait for a ticket of a step whose batch is still open
  * flushes the batch first, so streaming callers (one frame per call) see batches of one. */
 #define VENC_EBATCH 4
+/* INTRA AHEAD.  The I pictures of a scheduling unit depend on nothing before them (closed GOPs), and their kernel chain is
+ * the slowest of the pass for what it computes: k_intra_dc walks a dependency wavefront on a few CUs for ~110 us.  With a
+ * ring of VENC_RECON reconstruction buffers the I step is launched on a THIRD stream as soon as the buffer it will write is
+ * idle -- the P step VENC_RECON - 1 before it has finished with it -- and runs beside the last P steps of the previous unit instead
+ * of between the units.  The main stream picks the chain up again with the first P step (one event). */
+#define VENC_RECON 8 /* (the buffer step N writes was read last by step N - 7: at least four steps of overlap with batches of four) */
+#define VENC_BHIST 8
 
 struct venc_ctx {
     venc_config cfg;
@@ -94,7 +101,21 @@ struct venc_ctx {
     int n_events;
     int ev_done; /* newest ticket known to be complete (-1: none) */
     int ev_next;
-    int parity;
+    int parity;           /* reconstruction buffer the next step writes; rec_last: the one the last step wrote (the next reference) */
+    int rec_last;
+    hipStream_t stream3;  /* intra steps running ahead */
+    hipEvent_t ev_intra;  /* the last intra step on stream3 done */
+    int intra_pending;    /* ev_intra recorded and not yet waited for by the main stream */
+    int intra_async_last; /* the open entropy batch holds an intra step that ran on stream3 */
+    int intra_ahead;      /* 1 (default): intra steps on stream3 (VENC_INTRA_AHEAD=0: on the main stream) */
+    /* the last entropy batches: the step each ended with, an event behind its main chains (stream 1) and one behind its
+     * chroma transforms (stream 2): what an intra step running ahead waits for */
+    struct {
+        long long last_step;
+        hipEvent_t ev_main, ev_chroma;
+        int has_chroma;
+    } bh[VENC_BHIST];
+    int bh_next;
     long long step_no; /* steps issued so far; ring slot of a step = step_no % VENC_RING */
     uint8_t *d_in;        /* internal input pool (may be null) */
     int in_frames;        /* frames addressable through b.in_base */
@@ -219,6 +240,13 @@ extern "C" void venc_close(venc_ctx *c) {
         if (c->ev_luma[i]) (void)hipEventDestroy(c->ev_luma[i]);
     }
     if (c->ev_chroma) (void)hipEventDestroy(c->ev_chroma);
+    if (c->stream3) (void)hipStreamSynchronize(c->stream3);
+    if (c->ev_intra) (void)hipEventDestroy(c->ev_intra);
+    for (int i = 0; i < VENC_BHIST; i++) {
+        if (c->bh[i].ev_main) (void)hipEventDestroy(c->bh[i].ev_main);
+        if (c->bh[i].ev_chroma) (void)hipEventDestroy(c->bh[i].ev_chroma);
+    }
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
     for (int i = 0; i < VENC_RING; i++)
         if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
@@ -361,6 +389,15 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_luma[i], hipEventDisableTiming));
     }
     OPEN_OK(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    OPEN_OK(hipEventCreateWithFlags(&c->ev_intra, hipEventDisableTiming));
+    for (int i = 0; i < VENC_BHIST; i++) {
+        OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_main, hipEventDisableTiming));
+        OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_chroma, hipEventDisableTiming));
+        c->bh[i].last_step = -1;
+    }
+    c->intra_ahead = !(getenv("VENC_INTRA_AHEAD") && atoi(getenv("VENC_INTRA_AHEAD")) == 0);
+    c->rec_last = VENC_RECON - 1;
     c->fuse_luma = !(getenv("VENC_FUSE") && atoi(getenv("VENC_FUSE")) == 0);
     for (int i = 0; i < VENC_RING; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
@@ -451,8 +488,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     /* the internal input pool is allocated on first use (venc_upload / venc_input_slot_ptr):
      * resident-input users (venc_set_input) never pay for it */
     b.recon_frame_bytes = (size_t)g.cw * g.ch * 3 / 2;
-    OPEN_OK(hipMalloc(&b.recon, 2 * G * b.recon_frame_bytes));
-    OPEN_OK(hipMemset(b.recon, 128, 2 * G * b.recon_frame_bytes));
+    OPEN_OK(hipMalloc(&b.recon, VENC_RECON * G * b.recon_frame_bytes));
+    OPEN_OK(hipMemset(b.recon, 128, VENC_RECON * G * b.recon_frame_bytes));
     /* mvsad, levels and mbinfo: a ring of VENC_RING step slots (see VENC_RING) */
     OPEN_OK(hipMalloc(&b.mvsad, VENC_RING * G * nmb * 4));
     OPEN_OK(hipMemset(b.mvsad, 0, VENC_RING * G * nmb * 4));
@@ -651,6 +688,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.is_idr = is_idr ? 1 : 0;
     S.frame_num = frame_num;
     S.parity = c->parity;
+    S.ref = c->rec_last;
     S.me_stop = c->me_stop;
     S.slice0 = c->band_s0;
     S.slice1 = c->band_s1;
@@ -659,6 +697,8 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.mb0 = S.row0 * c->g.mbw;
     S.mb1 = S.row1 * c->g.mbw;
     const int band_rows = S.row1 - S.row0, band_mbs = S.mb1 - S.mb0, band_slices = S.slice1 - S.slice0;
+    /* intra steps run ahead on a third stream (VENC_RECON) unless the engine codes a band or the legacy kernel */
+    const bool intra_async = is_idr && c->intra_ahead && c->overlap && !c->intra_legacy && c->me_mode == 0 && !c->rc_comm && c->band_s0 == 0 && c->band_s1 == c->g.n_slices;
     for (int i = 0; i < n_items; i++) {
         if (in_slots[i] < 0 || in_slots[i] >= c->in_frames || out_slots[i] < 0 || out_slots[i] >= c->cfg.out_slots) {
             SET_ERR("venc_encode_step: slot out of range (item %d: in %d, out %d)", i, in_slots[i], out_slots[i]);
@@ -668,7 +708,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         S.out_slot[i] = out_slots[i];
         if (c->staged) c->fetched[out_slots[i]] = 0;
         if (c->d_in && c->b.in_base == c->d_in && c->copy_pending[in_slots[i]]) { /* the frame's ingest copy precedes the step */
-            HIP_OK(hipStreamWaitEvent(c->stream, c->ev_copy[in_slots[i]], 0));
+            HIP_OK(hipStreamWaitEvent(intra_async ? c->stream3 : c->stream, c->ev_copy[in_slots[i]], 0));
             c->copy_pending[in_slots[i]] = 0;
         }
         S.idr_id[i] = idr_ids ? idr_ids[i] : 0;
@@ -695,8 +735,36 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         const long long need = c->step_no + VENC_RING_WAIT - 1 - VENC_RING;
         if (need >= 0 && c->side_step[need % VENC_RING] == need) HIP_OK(hipStreamWaitEvent(s1, c->ev_side[need % VENC_RING], 0));
     }
+    /* the first P step after intra steps that ran ahead joins their stream */
+    if (!is_idr && c->intra_pending) {
+        HIP_OK(hipStreamWaitEvent(s1, c->ev_intra, 0));
+        c->intra_pending = 0;
+    }
     if (is_idr) {
-        HIP_OK(main_waits_for_chroma(c)); /* the intra kernels overwrite chroma planes the last P step's chroma launch may still read */
+        if (intra_async) {
+            /* The buffer this step writes (ring index step % VENC_RECON) was written by step - VENC_RECON and read last by
+             * step - VENC_RECON + 1 (its search and transforms on stream 1, its chroma transform on stream 2): wait for the
+             * EARLIEST entropy batch that ended at or after that step -- both its events; batches complete in order -- and,
+             * for the ring slot of levels and records, for the entropy chain that last read it.  Nothing else orders this
+             * step: it reads input pictures only.  (No such batch in the history: those steps do not exist.) */
+            s1 = c->stream3;
+            int best = -1;
+            const long long last_reader = c->step_no - VENC_RECON + 1;
+            for (int i = 0; i < VENC_BHIST; i++)
+                if (c->bh[i].last_step >= 0 && c->bh[i].last_step >= last_reader && (best < 0 || c->bh[i].last_step < c->bh[best].last_step)) best = i;
+            if (best >= 0) {
+                HIP_OK(hipStreamWaitEvent(s1, c->bh[best].ev_main, 0));
+                if (c->bh[best].has_chroma) HIP_OK(hipStreamWaitEvent(s1, c->bh[best].ev_chroma, 0));
+            }
+            const long long need = c->step_no - VENC_RING;
+            if (need >= 0 && c->side_step[rs] == need) HIP_OK(hipStreamWaitEvent(s1, c->ev_side[rs], 0));
+        } else {
+            if (c->intra_pending) { /* (a synchronous intra step behind asynchronous ones: band mode switched on in between) */
+                HIP_OK(hipStreamWaitEvent(s1, c->ev_intra, 0));
+                c->intra_pending = 0;
+            }
+            HIP_OK(main_waits_for_chroma(c)); /* the intra kernels overwrite chroma planes the last P step's chroma launch may still read */
+        }
         prof_begin(c, KID_INTRA, s1);
 #ifdef VENC_LEGACY_KERNELS
         if (c->intra_legacy)
@@ -710,6 +778,11 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_intra_rec, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
         }
         prof_end(c, s1);
+        if (intra_async) {
+            HIP_OK(hipEventRecord(c->ev_intra, s1));
+            c->intra_pending = 1;
+            s1 = c->stream;
+        }
     } else {
         /* Two sets of fix counters alternate between P steps: this step's search fills one and zeroes the other (the
          * legacy searches do not: a memset node instead). */
@@ -791,9 +864,11 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         c->eb_step[k] = S;
         if (k == 0) c->eb_chroma = 0;
         if (chroma_deferred) c->eb_chroma = 1;
+        c->intra_async_last = intra_async;
         c->eb_n++;
     }
-    c->parity ^= 1;
+    c->rec_last = c->parity;
+    c->parity = (c->parity + 1) % VENC_RECON;
     c->step_no++;
     c->steps_done++;
     /* closed: I pictures (their own kernel), ragged steps, the last slot of the group, a full batch */
@@ -822,11 +897,18 @@ static int entropy_flush(venc_ctx *c) {
     b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.vcap * VENC_COUNTER_STRIDE;
     if (!is_idr) c->unit_phase ^= 1;
     hipStream_t s1 = c->stream, s2 = c->overlap ? c->stream2 : c->stream;
+    const int hi = c->bh_next;
     if (c->overlap) {
-        hipEvent_t em = c->ev_main[c->ev_main_next];
-        c->ev_main_next ^= 1;
-        HIP_OK(hipEventRecord(em, s1));
-        HIP_OK(hipStreamWaitEvent(s2, em, 0));
+        if (is_idr && c->intra_async_last) {
+            HIP_OK(hipStreamWaitEvent(s2, c->ev_intra, 0)); /* the intra step ran on stream3 */
+            c->bh[hi].last_step = -1;                       /* (not a batch an intra step running ahead could wait for) */
+        } else {
+            HIP_OK(hipEventRecord(c->bh[hi].ev_main, s1));
+            HIP_OK(hipStreamWaitEvent(s2, c->bh[hi].ev_main, 0));
+            c->bh[hi].last_step = c->eb_first_step + n_steps - 1;
+            c->bh[hi].has_chroma = 0;
+            c->bh_next = (hi + 1) % VENC_BHIST;
+        }
     }
     if (c->eb_chroma) {
         for (int k = 0; k < n_steps; k++) {
@@ -842,6 +924,10 @@ static int entropy_flush(venc_ctx *c) {
         if (c->overlap) {
             HIP_OK(hipEventRecord(c->ev_chroma, s2));
             c->chroma_pending = 1;
+            if (c->bh[hi].last_step >= 0) {
+                HIP_OK(hipEventRecord(c->bh[hi].ev_chroma, s2));
+                c->bh[hi].has_chroma = 1;
+            }
         }
         c->eb_chroma = 0;
     }
@@ -956,7 +1042,11 @@ static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride
     for (int i = 0; i < J.n_seg; i++) big = J.seg[i].bytes > big ? J.seg[i].bytes : big;
     int blocks = (int)((big / 16 + 1023) / 1024); /* four trips per lane */
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_band_copy, dim3(blocks, J.n_seg, n_items), dim3(256), 0, c->stream, c->b, c->parity ^ 1, J, (uint8_t *)d_chunk);
+    if (c->intra_pending) { /* (band engines code their intra steps on the main stream; an engine may change mode) */
+        HIP_OK(hipStreamWaitEvent(c->stream, c->ev_intra, 0));
+        c->intra_pending = 0;
+    }
+    hipLaunchKernelGGL(k_band_copy, dim3(blocks, J.n_seg, n_items), dim3(256), 0, c->stream, c->b, c->rec_last, J, (uint8_t *)d_chunk);
     HIP_OK(hipGetLastError());
     return bytes;
 }
@@ -1021,6 +1111,7 @@ extern "C" int venc_wait_issued(venc_ctx *c, int ticket) {
 extern "C" int venc_sync(venc_ctx *c) {
     if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream_copy));
+    HIP_OK(hipStreamSynchronize(c->stream3));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     return 0;
@@ -1030,9 +1121,11 @@ extern "C" int venc_sync(venc_ctx *c) {
  * chain; 0: every kernel on one stream (isolated per-kernel timings for the roofline report) */
 extern "C" int venc_set_overlap(venc_ctx *c, int enable) {
     if (entropy_flush(c) != 0) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream3));
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     c->chroma_pending = 0;
+    c->intra_pending = 0;
     c->overlap = enable ? 1 : 0;
     for (int i = 0; i < VENC_RING; i++) c->side_step[i] = -1; /* both streams are idle: nothing to wait for */
     return 0;
@@ -1105,7 +1198,8 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
     const size_t nmb = (size_t)g.nmb;
     const void *src = NULL;
     size_t n = 0;
-    const int last_parity = c->parity ^ 1;
+    HIP_OK(hipStreamSynchronize(c->stream3));
+    const int last_parity = c->rec_last;
     const size_t lp_off = (size_t)((c->step_no + VENC_RING - 1) % VENC_RING) * c->b.max_items; /* ring slot of the last step */
     const uint8_t *rec = c->b.recon + (size_t)(last_parity * c->b.max_items + item) * c->b.recon_frame_bytes;
     switch (what) {

@@ -219,7 +219,7 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
     const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
     int cstride, pw, ph, rstride;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
 
     uint32_t cq[4], pq[4]; /* current and predicted rows, four samples per dword */
     load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, cq);
@@ -250,7 +250,7 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
     int cstride, pw, ph, rstride, wstride;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, plane, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, plane, rstride);
     uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
     const int rw = g.cw >> 1, rh = g.ch >> 1;
 

@@ -4,7 +4,8 @@
  *
  * HBM layout (one encoder context, G = max items per step):
  *   input pool    [slots][ Y w*h | U w*h/4 | V w*h/4 ]      display size, tight I420
- *   recon         [2][G][ Y cw*ch | U | V ]                  coded size, ping-pong by frame parity
+ *   recon         [8][G][ Y cw*ch | U | V ]                  coded size, a ring of eight: the intra pictures of the next unit are
+ *                                                            coded beside the last P steps of this one (venc_hip.hip)
  *   mvsad         [G][nmb] u32   = sad<<16 | (dy&255)<<8 | (dx&255)
  *   levels        [G][nmb][27][16] i16   (block order documented in include/venc_hip.h)
  *   mbinfo        [G][nmb] 32 B  = nnz[24] (16 luma raster, 4 Cb, 4 Cr), cbp, flags
@@ -68,7 +69,8 @@ typedef struct {
     int n_items;
     int is_idr;
     int frame_num;
-    int parity; /* recon buffer written this step; the other one is the reference */
+    int parity; /* recon buffer written this step (index into the ring of VENC_RECON buffers) */
+    int ref;    /* recon buffer of the previous picture of the chain: the reference of a P step */
     /* band of the picture coded by this context (slice-parallel multi-GPU mode, venc_set_band);
      * the whole picture by default: slices [slice0, slice1) = MB rows [row0, row1) = macroblocks [mb0, mb1) */
     int slice0, slice1, row0, row1, mb0, mb1;

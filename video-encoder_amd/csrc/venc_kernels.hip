@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_me_dense(venc_geom g, venc_bufs B, venc
     const int item = blockIdx.z, my = S.row0 + blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
     const int x0 = tx * ME_TILE * 16, y0 = my * 16;
     int rstride;
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     int cstride, pw, ph;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
 
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_st
 
     int cstride, pw, ph, rstride, wstride;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, plane, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, plane, rstride);
     uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
     const int rw = luma ? g.cw : g.cw >> 1, rh = luma ? g.ch : g.ch >> 1;
 

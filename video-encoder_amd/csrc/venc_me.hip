@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_me(venc_geom g, venc_bufs B, venc_step 
     const int item = blockIdx.z, my = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
     const int x0 = tx * ME_TILE * 16, y0 = my * 16;
     int rstride;
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     int cstride, pw, ph;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
 

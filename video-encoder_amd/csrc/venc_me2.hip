@@ -71,7 +71,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
     const int item = blockIdx.z, tid = threadIdx.x;
     const int x0 = blockIdx.x * T2_MBX * 16, y0 = (S.row0 + blockIdx.y * T2_MBY) * 16;
     int rstride, cstride, pw, ph;
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
     /* every global load whose result is needed late is issued here, ahead of the window staging, so
      * that no memory round trip sits alone on the critical path: the tie-break ranks (written to LDS
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
     if (blockIdx.x >= count) return;
     int rstride, cstride, pw, ph;
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
     const int dy0 = wave * FIX_NDY;          /* first dy index of this wave */
     const int dxi = lane < 33 ? lane : 32;   /* lanes 33..63 repeat column 32 and are ignored */

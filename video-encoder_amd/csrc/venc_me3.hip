@@ -127,7 +127,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const bool mb_valid = mx < g.mbw && my < S.row1;
     const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
     int rstride, cstride, pw, ph;
-    const uint8_t *ref = rec_plane(B, g, S.parity ^ 1, item, 0, rstride);
+    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
 
     /* ---- P0: every global load of the block is issued here, then the window, the current tile and the
