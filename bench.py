@@ -323,14 +323,26 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                         traffic = json.load(open(tfile)).get(wl_key, {}).get("k_me_hbm_bytes_per_launch")
                     except Exception:
                         traffic = None
-                res["roofline"] = {"bound": "hbm", "kernel": "k_me", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                res["roofline"] = {"bound": "hbm", "kernel": "k_me_pool = exact +-16 full search + luma 4x4 transform / quantisation / reconstruction, fused (the ME+DCT kernel)",
+                                   "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                                    "algorithmic_bytes_per_launch": int(algo_bytes),
                                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": me_n, "launches_sampled_one_in": ME_EVENT_STRIDE,
                                    "search_positions_per_s": round(1089.0 * 256.0 * px_per_launch / 256.0 / avg_s, 1),
                                    "timed_region_runs_two_kernel_chains_concurrently": True,
                                    "events_dropped": dropped,
-                                   "note": "HBM is the bound this line is priced against; the kernel itself is VALU/LDS bound (DESIGN.md 4.1)"}
+                                   "note": "HBM is the bound this line is priced against; the kernel itself is VALU/LDS bound (DESIGN.md 4.1). "
+                                           "Algorithmic bytes = 2.0 B per P-frame pixel read (cur Y + ref Y); since round 2 the same launch also does the luma "
+                                           "transform that round 1 ran as a separate kernel, so its duration is not comparable with round 1's search-only k_me_pool"}
+                # the whole P path of SURVEY.md section 8d (3.0 B/px read: cur Y+U+V 1.5, ref Y 1.0, ref U+V 0.5) over one main-chain period
+                if prof_all:
+                    chain_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in ("k_me", "k_me_fix", "k_inter"))
+                    n_p = prof_all.get("k_me", (0.0, 0))[1]
+                    if n_p:
+                        per = chain_ms / n_p * 1e-3
+                        res["roofline"]["p_path"] = {"algorithmic_bytes_per_step": int(1.5 * algo_bytes), "kernels": "k_me_pool + k_me_fix + chroma k_inter_fused",
+                                                     "sum_of_kernel_us": round(per * 1e6, 2), "achieved": round(1.5 * algo_bytes / per / 1e9, 2),
+                                                     "frac": round(1.5 * algo_bytes / per / 1e9 / HBM_PEAK_GBS, 5)}
                 iso_ms, iso_n = prof_iso.get("k_me", (0.0, 0))
                 if iso_n:
                     iso_s = iso_ms / iso_n * 1e-3

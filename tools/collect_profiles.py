@@ -11,7 +11,8 @@ import sys
 
 src, tag = sys.argv[1], sys.argv[2]
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
-names = {"bench_1080p": "bench_1080p", "bench_2160p": "bench_2160p", "bench_1080p_serial": "bench_1080p_serial_steps",
+names = {"bench_default": "bench_default_1080p_with_2160p_pcie_cpu_bitexact", "bench_1080p": "bench_1080p", "bench_2160p": "bench_2160p",
+         "bench_1080p_serial": "bench_1080p_serial_steps",
          "bench_2160p_serial": "bench_2160p_serial_steps", "bench_slices1": "bench_2160p_slices_1rank",
          "bench_slices2": "bench_2160p_slices_2rank_gloo_rehearsal", "bench_streams2": "bench_1080p_streams_2rank_gloo_rehearsal"}
 for a, b in names.items():
@@ -38,4 +39,8 @@ for wl in ("1080p", "2160p"):
             for r in csv.DictReader(open(cc[0])):
                 w.writerow([r["Dispatch_Id"], r["Kernel_Name"].split("(")[0], r["Grid_Size"], r["Counter_Name"], r["Counter_Value"],
                             r["Start_Timestamp"], r["End_Timestamp"]])
+for wl in ("1080p", "2160p"):
+    p = os.path.join(src, "sq_counters_%s_isolated.txt" % wl)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, "%s_sq_counters_%s_isolated.txt" % (tag, wl)))
 print("\n".join(sorted(f for f in os.listdir(dst) if f.startswith(tag))))

@@ -5,26 +5,38 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd $R
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/test.log 2>&1; tail -2 $O/test.log
+Q="--no-extras --cpu-frames 0"
 cd /tmp; export TMPDIR=/tmp
 for wl in 1080p 2160p; do
-  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$wl -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 --cpu-frames 0 --no-profile > $O/pmcf_$wl.log 2>&1 &&
-  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_$wl -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 --cpu-frames 0 --no-profile > $O/pmcw_$wl.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$wl -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 $Q --no-profile > $O/pmcf_$wl.log 2>&1 &&
+  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcw_$wl -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 $Q --no-profile > $O/pmcw_$wl.log 2>&1
+  echo "pmc $wl done"
 done
 cd $R
 for wl in 1080p 2160p; do python3 tools/pmc_summary.py $O/pmcf_$wl $O/pmcw_$wl $wl > /dev/null; done
 cp profiles/pmc_traffic.json $O/
-timeout -k 10 300 python bench.py > $O/bench_1080p.json 2> $O/bench_1080p.err; cut -c1-240 $O/bench_1080p.json
-timeout -k 10 300 python bench.py --workload 2160p --cpu-frames 0 > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
-timeout -k 10 300 python bench.py --serial-steps --cpu-frames 0 > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
-timeout -k 10 300 python bench.py --serial-steps --workload 2160p --cpu-frames 0 > $O/bench_2160p_serial.json 2> $O/bench_2160p_serial.err
+timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-240 $O/bench_default.json
+timeout -k 10 300 python bench.py --workload 2160p $Q > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
+timeout -k 10 300 python bench.py --serial-steps $Q > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
 cd /tmp
 for wl in 1080p 2160p; do
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --cpu-frames 0 > $O/stats_$wl.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$wl -- python3 $R/bench.py --workload $wl --steps 3 --warmup 2 $Q > $O/stats_$wl.log 2>&1
+  echo "stats $wl done"
+done
+# SQ counters, every kernel alone on the chip (one stream)
+for wl in 1080p 2160p; do
+  for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM"; do
+    VENC_NO_OVERLAP=1 timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/sq_$wl/${c%% *} -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 $Q --no-profile > $O/sq_$wl.log 2>&1
+  done
+  echo "sq $wl done"
 done
 cd $R
-timeout -k 10 300 python bench.py --steps 3 --warmup 1 --mode slices --workload 2160p --cpu-frames 0 > $O/bench_slices1.json 2> $O/bench_slices1.err; cut -c1-240 $O/bench_slices1.json
-timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --steps 3 --warmup 1 --gpus 2 --mode slices --workload 2160p --backend gloo --device 0 --cpu-frames 0 > $O/bench_slices2.json 2> $O/bench_slices2.err
-grep -o '"bitstream_sha256": "[0-9a-f]*"' $O/bench_slices1.json $O/bench_slices2.json
-timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --steps 3 --warmup 1 --gpus 2 --backend gloo --device 0 --cpu-frames 0 > $O/bench_streams2.json 2> $O/bench_streams2.err
+for wl in 1080p 2160p; do python3 tools/sq_summary.py $O/sq_$wl $wl > $O/sq_counters_${wl}_isolated.txt 2> $O/sq_summary_$wl.err; done
+timeout -k 10 300 python bench.py --steps 3 --warmup 2 --mode slices --workload 2160p $Q > $O/bench_slices1.json 2> $O/bench_slices1.err; cut -c1-240 $O/bench_slices1.json
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --steps 3 --warmup 1 --gpus 2 --mode slices --workload 2160p --backend gloo --device 0 $Q > $O/bench_slices2.json 2> $O/bench_slices2.err
+grep -o '"bitstream_sha256": "[0-9a-f]*"' $O/bench_slices2.json
+timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --steps 3 --warmup 1 --gpus 2 --backend gloo --device 0 $Q > $O/bench_streams2.json 2> $O/bench_streams2.err
 cut -c1-200 $O/bench_streams2.json
+# keep the merged output small: the raw traces stay on the box
+for d in $O/pmcf_* $O/pmcw_* $O/stats_* $O/sq_1080p $O/sq_2160p; do [ -d "$d" ] && find $d -name "*agent_info.csv" -delete; done
+du -sh $O

@@ -398,7 +398,12 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     }
     c->intra_ahead = !(getenv("VENC_INTRA_AHEAD") && atoi(getenv("VENC_INTRA_AHEAD")) == 0);
     c->rec_last = VENC_RECON - 1;
-    c->fuse_luma = !(getenv("VENC_FUSE") && atoi(getenv("VENC_FUSE")) == 0);
+    /* 0: k_inter_fused (luma + chroma) on the main chain; 1 (default): luma transform inside the search kernels, chroma on stream 2;
+     * 2: chroma inside the search kernels too (waves 4-5 of P5): bit-exact, measured SLOWER -- the chroma samples come from memory
+     * and their latency lengthens every block's tail while it holds a third of a CU's LDS (1080p 149 -> 141 Gpx/s, search alone
+     * 85 -> 104 us; 2160p 196 -> 179) */
+    c->fuse_luma = getenv("VENC_FUSE") ? atoi(getenv("VENC_FUSE")) : 1;
+    if (c->fuse_luma < 0 || c->fuse_luma > 2) c->fuse_luma = 1;
     for (int i = 0; i < VENC_RING; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
         c->side_step[i] = -1;
@@ -790,6 +795,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         b.fix_count_next = c->b.fix_count + (size_t)(c->fix_phase ^ 1) * c->b.max_items;
         c->fix_phase ^= 1;
         const bool fuse = c->fuse_luma && c->me_mode == 0 && !c->inter_legacy;
+        const int fuse_arg = !fuse ? 0 : c->fuse_luma; /* 1: luma in the search kernels; 2: chroma too */
         if (c->me_mode != 0) HIP_OK(hipMemsetAsync(b.fix_count_next, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
 #ifdef VENC_LEGACY_KERNELS
@@ -809,13 +815,13 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             const int runs = (ntx * nty + 63) / 64;
             const uint32_t tx_magic = ntx > 1 ? (uint32_t)((0x100000000ull + (uint64_t)ntx - 1) / (uint64_t)ntx) : 0u;
             const int gx = c->me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
-            hipLaunchKernelGGL(k_me_pool, dim3(gx, 1, n_items), dim3(512), 0, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse ? 1 : 0);
+            hipLaunchKernelGGL(k_me_pool, dim3(gx, 1, n_items), dim3(512), 0, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
         }
         prof_end(c, s1);
         const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */
         if (flags_mbs) {
             prof_begin(c, KID_MEFIX, s1);
-            hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(256), 0, s1, g, b, S, fuse ? 1 : 0);
+            hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(64 * FIX_WAVES), 0, s1, g, b, S, fuse_arg);
             prof_end(c, s1);
         }
 #ifdef VENC_LEGACY_KERNELS
@@ -836,7 +842,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
              * needs nothing else (it reads luma only).  The chroma transforms of a batch of steps follow on the second
              * stream, one after the other (chroma reconstructions chain from step to step), ahead of the batch's entropy
              * chain and beside the next searches: ONE event hand-off per batch, none between the kernels of the main chain. */
-            chroma_deferred = true;
+            chroma_deferred = c->fuse_luma < 2;
         }
     }
 #ifdef VENC_LEGACY_KERNELS

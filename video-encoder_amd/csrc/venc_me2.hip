@@ -302,12 +302,15 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
  * displacement.  k_me_tile appended the macroblock indices to fix_list / fix_count. */
 #define FIX_BLOCKS 256 /* per item: one listed macroblock per block in all but pathological pictures (a block that loops costs the step a second search latency) */
 #define FIX_WD 13 /* window row: 48 bytes + 4 spare, in dwords */
-#define FIX_NDY 9
+#define FIX_NDY 9   /* vertical displacements per wave: 4 waves cover 36 >= 33.  (8 waves x 5: k_me_fix 17 -> 26 us per launch, 1080p 149 -> 143
+                       Gpx/s; 16 x 3 spills at the 128-register cap of a 1024-thread block.  Every wave pays the 64 LDS reads of the
+                       current block and the block-wide barriers whatever its share of the search.) */
+#define FIX_WAVES 4
 
-__global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_step S, int fuse_luma) {
+__global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_bufs B, venc_step S, int fuse_luma) {
     __shared__ uint32_t s_win[(48 + 4) * FIX_WD];
     __shared__ uint32_t s_cur[16 * 4];
-    __shared__ uint32_t s_best[4];
+    __shared__ uint32_t s_best[FIX_WAVES];
     __shared__ int s_mv[2];
     const int item = blockIdx.z, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
             uint32_t *d = s_win + r * FIX_WD + 4 * q; /* rows are 52 bytes apart: dword stores */
             d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
             if (q == 0) s_win[r * FIX_WD + 12] = 0;
-        } else if (tid >= 192) {
+        } else if (tid >= 192 && tid < 256) {
             const int t = tid - 192, r = t >> 2, d = t & 3;
             const uint8_t *row = cur + (size_t)min(y0 + r, g.h - 1) * cstride;
             const int xb = x0 + 4 * d;
@@ -391,7 +394,9 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
         const uint32_t wm = min((uint32_t)__builtin_amdgcn_readlane((int)hm, 0), (uint32_t)__builtin_amdgcn_readlane((int)hm, 32));
         if (lane == 0) s_best[wave] = wm;
         __syncthreads();
-        const uint32_t best = min(min(s_best[0], s_best[1]), min(s_best[2], s_best[3]));
+        uint32_t best = s_best[0];
+#pragma unroll
+        for (int k = 1; k < FIX_WAVES; k++) best = min(best, s_best[k]);
         if (mine == best) {
             const int dx = dxi - 16, dy = dy0 + mine_k - 16;
             B.mvsad[(size_t)item * g.nmb + mb] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
@@ -414,6 +419,8 @@ __global__ __launch_bounds__(256) void k_me_fix(venc_geom g, venc_bufs B, venc_s
                 }
                 luma_block_code(g, B, S, item, lane, mb, lane < 16, cq, pq);
             }
+            if (fuse_luma > 1 && tid >= 64 && tid < 128) /* its chroma transform: lanes 0-7 of wave 1 */
+                inter_chroma_mb(g, B, S, item, lane, mb, lane < 8, s_mv[0] - 16, s_mv[1] - 16);
         }
     }
 }

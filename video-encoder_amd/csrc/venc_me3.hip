@@ -416,6 +416,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
     }
     __syncthreads();
+    /* (indices once more from an opaque copy of the thread id: carried across the survivor scan and P4b, the 64-bit
+     * macroblock index was spilled to scratch -- 8 bytes per lane stored and reloaded by every wave) */
+    {
+    int tid_c = threadIdx.x;
+    asm volatile("" : "+v"(tid_c));
+    const int l32 = tid_c & 31, hw = tid_c >> 5;
+    const int mx = tx * T2_MBX + (hw & (T2_MBX - 1)), my = S.row0 + ty * T2_MBY + (hw >> 3);
+    const bool mb_valid = mx < g.mbw && my < S.row1;
+    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
     if (l32 == 0 && mb_valid) {
         const unsigned long long best = s_best[hw];
         const uint32_t ci = (uint32_t)best & 2047u, bcy = ci / 33u;
@@ -427,11 +436,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
     }
     }
+    }
     /* ---- P5: the luma transform of the tile's macroblocks, straight from the LDS copies the search used: current samples
      * from s_cur, prediction from the window at the winning displacement -> residual, 4x4 transform, quantisation,
      * dequantisation, inverse transform, reconstruction, levels (venc_inter2.hip luma_block_code).  16 macroblocks x 16
      * blocks = the lanes of waves 0-3; macroblocks listed for k_me_fix are left to it.  The transform no longer re-reads
      * the two luma planes from memory and costs the main chain no launch of its own. ---- */
+    if (fuse_luma > 1 && threadIdx.x >= 256 && threadIdx.x < 384) {
+        /* ... and the chroma transform of the same macroblocks on waves 4 and 5, which would otherwise have left: 8 lanes
+         * per macroblock, samples from memory (the chroma planes are not in LDS), venc_inter2.hip inter_chroma_mb.  No chroma
+         * launch is left on either stream. */
+        const int t6 = threadIdx.x - 256, m = t6 >> 3;
+        const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
+        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] == 0u;
+        const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
+        inter_chroma_mb(g, B, S, item, t6 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, (int)bcx - 16, (int)bcy - 16);
+    }
     if (fuse_luma && threadIdx.x < 256) {
         const int t5 = threadIdx.x, m = t5 >> 4, blk = t5 & 15;
         const int mcol0 = (m & (T2_MBX - 1)) * 16, mrow0 = (m >> 3) * 16;
