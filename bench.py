@@ -208,6 +208,8 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             return enc.encode_resident_tally(clip.data_ptr(), fb, frames)
         mine = []
         enc.encode_resident(clip.data_ptr(), fb, frames, sink=lambda payload, nals, pts, key: mine.append(payload))
+        if c_exchange and venc.hip_lib().venc_rccl_agree(enc.L.x264_venc_engine(enc.h), 0) != 0:
+            raise SystemExit("bench: a rank reported a failure (venc_rccl_agree)")  # every rank stops together
         parts = dmod.gather_frames_to_root(mine)  # rank 0 only: the bitstream is assembled where it is written out
         if rank == 0:
             whole = dmod.interleave_bands(parts)

@@ -188,3 +188,33 @@ def test_gloo_slice_parallel_bands_reproduce_the_single_stream(world, halo_rows,
         assert p.exitcode == 0
     assert all(same), same
     assert exchanges == 7 and nbytes > 2000  # 9 frames, keyint 4: exchange after frames 0,1,2,4,5,6,8
+
+
+def _root_gather_rank(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    d = importlib.import_module("video-encoder_amd.dist")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = [bytes([rank, t]) * (3 + rank) for t in range(5)]
+    parts = d.gather_frames_to_root(frames)
+    if rank == 0:
+        q.put(d.interleave_bands(parts))
+    else:
+        assert parts is None  # the other ranks receive nothing
+    dist.destroy_process_group()
+
+
+def test_bitstreams_are_gathered_on_rank_zero_only():
+    """bench.py --mode slices: the bands' payloads go to the rank that writes the stream out, not to every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + os.getpid() % 40
+    procs = [ctx.Process(target=_root_gather_rank, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    whole = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert whole == [b"".join(bytes([r, t]) * (3 + r) for r in range(3)) for t in range(5)]

@@ -242,6 +242,47 @@ def test_intra_three_kernels_equal_the_wavefront_kernel(venc, legacy_lib, w, h, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [
+    {"VENC_FUSE": "0"},                 # luma + chroma transform as k_inter_fused on the main chain (round 1's shape)
+    {"VENC_FUSE": "2"},                 # chroma transform inside the search kernels too
+    {"VENC_ENTROPY_BATCH": "1"},        # entropy chain per step
+    {"VENC_ENTROPY_BATCH": "2"},
+    {"VENC_INTRA_AHEAD": "0"},          # I steps on the main stream
+    {"VENC_STAGED": "0"},               # k_pack stores to pinned host memory
+    {"VENC_STAGED": "1", "VENC_HOST_THREADS": "1"},   # staged output, no packaging thread
+    {"VENC_NO_OVERLAP": "1"},           # one stream
+    {"VENC_ME_LDS_PAD": "28000"},       # two search blocks per CU
+])
+def test_launcher_variants_change_nothing(venc, orc, monkeypatch, env):
+    """Every scheduling variant of the launcher -- where the transforms run, how many steps an entropy
+    launch covers, where I steps run, how the bitstream leaves the GPU, how many host threads -- must give the default's
+    stream, which equals the oracle's.  Three passes of a clip with short GOPs in lock-step, so that units overlap,
+    batches wrap around the ring and intra steps run ahead of their unit."""
+    import torch
+    w, h, n, keyint, reps = 352, 288, 24, 6, 3
+    fb = w * h * 3 // 2
+    buf = torch.empty(n * fb, dtype=torch.uint8, device="cuda")
+    assert venc.hip_lib().venc_synth_device(buf.data_ptr(), fb, w, h, 0, n, 0x1234ABCD) == 0
+    outs = []
+    for e_ in (None, env):
+        for k, v in (e_ or {}).items():
+            monkeypatch.setenv(k, v)
+        e = venc.X264Encoder(w, h, qp=27, slices=4, keyint=keyint, gop_batch=2)
+        got = []
+        assert e.encode_resident(buf.data_ptr(), fb, n, lambda payload, nals, pts, key: got.append(payload), repeats=reps) == n * reps
+        e.close()
+        outs.append(got)
+    assert outs[0] == outs[1]
+    assert outs[0][:n] == outs[0][n:2 * n] == outs[0][2 * n:]
+    host = buf.cpu().numpy().reshape(n, fb)
+    ref = orc.Encoder(w, h, qp=27, n_slices=4, keyint=keyint, threads=8)
+    for t in range(n):
+        f = host[t]
+        assert outs[0][t] == ref.encode(f[:w * h].reshape(h, w), f[w * h:w * h * 5 // 4].reshape(h // 2, w // 2),
+                                        f[w * h * 5 // 4:].reshape(h // 2, w // 2)).data, "frame %d vs oracle" % t
+
+
+@pytest.mark.gpu
 def test_placement_knobs_change_nothing(venc, monkeypatch):
     """VENC_ENTROPY_CUS (the entropy chain's stream confined to a subset of the CUs) and VENC_ME_XCD (XCD-aware tile order
     of the motion search), experiments kept behind environment variables, must not change the stream."""
