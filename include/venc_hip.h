@@ -45,6 +45,9 @@ typedef struct {
     int in_slots;      /* input pool size in frames (0: caller will use venc_set_input) */
     int out_slots;     /* output pool size in frames */
     int device;        /* HIP device ordinal */
+    int rc_mode;       /* 0: every picture at qp; 1: picture QP chosen on the GPU from the previous picture's motion search
+                          (spec/CODEC.md section 1a: the frame-level approximation of libx264's CRF; qp = the rate factor,
+                          IDR pictures qp - 3, P pictures qp +- up to 6).  Whole-picture engines only. */
 } venc_config;
 
 /* Per-slice record of an encoded frame (raw RBSP: slice header + slice data +

@@ -52,6 +52,7 @@ typedef struct {
     int threads;         /* OpenMP threads (slice / MB-row parallel); <=0 -> 1 */
     int idr_base;        /* index of the first closed GOP (idr_pic_id = (idr_base + n) & 1): lets a
                             GOP-sharded run reproduce the single-encoder stream */
+    int rc_mode;         /* 0: fixed QP; 1: picture QP by spec/CODEC.md section 1a (qp = the base QP) */
 } orc_params;
 
 typedef struct {
@@ -96,6 +97,9 @@ void orc_idct4x4(const int32_t d[16], int16_t res[16]);     /* raster in, (x+32)
 int orc_quant(int coef, int qp, int raster_pos, int intra); /* AC/normal quantiser */
 int orc_dequant(int level, int qp, int raster_pos);
 int orc_me_rank(int dx, int dy);                            /* tie-break rank, 0..1088 */
+/* picture QP under rate control (spec/CODEC.md section 1a); have_history: the previous picture was a P picture of the same GOP */
+int orc_rc_qp(int base_qp, int is_idr, int have_history, uint64_t prev_sad_sum, int nmb);
+int orc_enc_picture_qp(const orc_enc *e);                   /* QP of the last encoded picture */
 /* CAVLC residual block; coef[] in scan order; returns number of bits appended */
 int orc_cavlc_block_bits(const int16_t *coef, int max_coef, int nC, uint8_t *out, size_t cap);
 /* emulation prevention: returns output size */

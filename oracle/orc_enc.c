@@ -170,6 +170,28 @@ static int dequant_chroma_dc(int f, int qpc) { /* 8.5.11.2 */
 }
 
 /* ------------------------------------------------------------------ ME rank */
+/* spec/CODEC.md section 1a */
+static int rc_ilog2q(uint32_t c) {
+    if (c < 1) c = 1;
+    int k = 31 - __builtin_clz(c);
+    int frac = k >= 2 ? (int)((c >> (k - 2)) & 3u) : (int)((c << (2 - k)) & 3u);
+    return 4 * k + frac;
+}
+int orc_rc_qp(int base_qp, int is_idr, int have_history, uint64_t prev_sad_sum, int nmb) {
+    int qp = base_qp;
+    if (is_idr)
+        qp = base_qp - 3;
+    else if (have_history) {
+        uint32_t c = (uint32_t)(prev_sad_sum / (uint64_t)(nmb > 0 ? nmb : 1));
+        int num = 3 * (rc_ilog2q(c) - 36);
+        int delta = num >= 0 ? num / 5 : -((-num + 4) / 5); /* floor division */
+        if (delta < -6) delta = -6;
+        if (delta > 6) delta = 6;
+        qp = base_qp + delta;
+    }
+    return qp < 12 ? 12 : qp > 51 ? 51 : qp;
+}
+
 int orc_me_rank(int dx, int dy) {
     /* position of (dx,dy) in the list of all 33x33 displacements sorted by
      * (|dx|+|dy|, dy, dx) ascending: deterministic tie-break preferring short vectors */
@@ -309,6 +331,9 @@ struct orc_enc {
     size_t *slice_len;
     uint8_t *esc_buf;
     int band_s0, band_s1; /* slices coded by this instance */
+    int qp_cur;           /* QP of the picture being coded (p.qp at fixed QP; spec/CODEC.md section 1a under rate control) */
+    uint64_t prev_sad_sum; /* sum of the best SADs of the previous picture's macroblocks */
+    int prev_was_p;
 };
 
 static int pick_level(int mbs, int fps_num, int fps_den) {
@@ -412,6 +437,7 @@ void orc_enc_close(orc_enc *e) {
     free(e);
 }
 
+int orc_enc_picture_qp(const orc_enc *e) { return e->qp_cur; }
 int orc_enc_mb_width(const orc_enc *e) { return e->mbw; }
 int orc_enc_mb_height(const orc_enc *e) { return e->mbh; }
 const int8_t *orc_enc_mv(const orc_enc *e) { return e->mv; }
@@ -481,7 +507,7 @@ static inline uint8_t clip_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 25
 static void code_chroma(orc_enc *e, int mx, int my, int plane, const uint8_t pred[64], int intra, int16_t *lv_dc,
                         int16_t *lv_ac /* [4][16] */) {
     int cs = e->cw / 2;
-    int qpc = orc_chroma_qp[e->p.qp];
+    int qpc = orc_chroma_qp[e->qp_cur];
     const uint8_t *cur = e->cur[plane] + (size_t)(my * 8) * cs + mx * 8;
     uint8_t *rec = e->rec[plane] + (size_t)(my * 8) * cs + mx * 8;
     int dc[4], ydc[4];
@@ -543,7 +569,7 @@ static int chroma_cbp_and_nnz(orc_enc *e, int mb, const int16_t *lv) {
 /* ---- Intra16x16 (DC prediction) macroblock: transform, quant, recon ---- */
 static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
     int mb = my * e->mbw + mx;
-    int qp = e->p.qp;
+    int qp = e->qp_cur;
     int avail_l = mx > 0, avail_t = my > slice_first_row;
     int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     memset(lv, 0, ORC_MB_COEFS * sizeof(int16_t));
@@ -650,7 +676,7 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
 /* ---- P_L0_16x16 macroblock: MC prediction, transform, quant, recon ---- */
 static void code_mb_inter(orc_enc *e, int mx, int my) {
     int mb = my * e->mbw + mx;
-    int qp = e->p.qp;
+    int qp = e->qp_cur;
     int dx = e->mv[2 * mb], dy = e->mv[2 * mb + 1];
     int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     memset(lv, 0, ORC_MB_COEFS * sizeof(int16_t));
@@ -941,11 +967,12 @@ static void write_slice_header(const orc_enc *e, bw_t *b, int first_mb, int idr)
         bw_put(b, 0, 1);
     } else
         bw_put(b, 0, 1); /* adaptive_ref_pic_marking_mode */
-    bw_se(b, 0);         /* slice_qp_delta */
+    bw_se(b, e->qp_cur - e->p.qp); /* slice_qp_delta: 0 at fixed QP */
     bw_ue(b, 1);         /* disable_deblocking_filter_idc */
 }
 
 int orc_enc_set_band(orc_enc *e, int slice_first, int slice_count) {
+    if (e->p.rc_mode && slice_count != e->p.n_slices) return -1; /* the rate control's SAD sum spans the picture */
     if (slice_first < 0 || slice_count < 1 || slice_first + slice_count > e->p.n_slices) return -1;
     e->band_s0 = slice_first;
     e->band_s1 = slice_first + slice_count;
@@ -979,11 +1006,17 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
 #ifdef _OPENMP
     omp_set_num_threads(e->p.threads);
 #endif
+    /* picture QP: fixed, or chosen from the previous picture's search results (spec/CODEC.md section 1a) */
+    e->qp_cur = e->p.rc_mode ? orc_rc_qp(e->p.qp, idr, e->prev_was_p, e->prev_sad_sum, e->mbw * e->mbh) : e->p.qp;
     if (!idr) {
 #pragma omp parallel for schedule(dynamic, 1)
         for (int my = e->slice_rows[e->band_s0]; my < e->slice_rows[e->band_s1]; my++)
             for (int mx = 0; mx < e->mbw; mx++) me_mb(e, mx, my);
+        uint64_t sum = 0;
+        for (int i = 0; i < e->mbw * e->mbh; i++) sum += e->sad[i];
+        e->prev_sad_sum = sum;
     }
+    e->prev_was_p = !idr;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int s = e->band_s0; s < e->band_s1; s++) {
         int r0 = e->slice_rows[s], r1 = e->slice_rows[s + 1];

@@ -18,7 +18,7 @@ MAX_NALS = 512
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "keyint", "fps_num", "fps_den",
-                                       "sar_w", "sar_h", "threads", "idr_base")]
+                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode")]
 
 
 class OrcNal(C.Structure):
@@ -64,6 +64,8 @@ def lib():
         L.orc_dequant.argtypes = [C.c_int] * 3
         L.orc_me_rank.argtypes = [C.c_int] * 2
         L.orc_cavlc_block_bits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_rc_qp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int]
+        L.orc_enc_picture_qp.argtypes = [C.c_void_p]
         L.orc_escape.restype = C.c_size_t
         L.orc_escape.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.orc_dec_open.restype = C.c_void_p
@@ -89,9 +91,10 @@ class Frame:
 
 
 class Encoder:
-    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0):
+    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False):
+        """rc: picture QP by spec/CODEC.md section 1a (the CRF approximation), qp = its base; else fixed QP."""
         self.L = lib()
-        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base)
+        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)))
         self.h = self.L.orc_enc_open(C.byref(self.params))
         if not self.h:
             raise ValueError("orc_enc_open rejected the parameters")
@@ -139,6 +142,9 @@ class Encoder:
             raise ValueError("orc_enc_import_rows: bad row range")
 
     # --- introspection of the last frame ---
+    def picture_qp(self):
+        return self.L.orc_enc_picture_qp(self.h)
+
     def mv(self):
         return np.ctypeslib.as_array(self.L.orc_enc_mv(self.h), (self.nmb, 2)).copy()
 

@@ -217,3 +217,22 @@ def test_zero_block_test_is_exactly_the_quantiser(hc, orc):
                 w = np.zeros(16, np.int32)
                 w[0] = 9000
                 assert hc.hc_block_all_zero(w.ctypes.data, qp, 1) == 1 and hc.hc_block_all_zero(w.ctypes.data, qp, 0) == 0
+
+
+def test_rate_control_rule_matches_the_oracle(hc, orc):
+    """spec/CODEC.md section 1a: the picture QP under rate control, product (venc_device.h, evaluated on the GPU by every
+    block of the search) against the oracle, over the whole argument space that matters; and the device-side construction of
+    a QP's quantiser constants against the host's."""
+    L = orc.lib()
+    hc.hc_rc_qp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_ulonglong, C.c_int]
+    rng = np.random.default_rng(5)
+    for base in (12, 20, 26, 40, 51):
+        for nmb in (1, 396, 8160, 32400):
+            sums = [0, 1, nmb - 1, nmb, 3 * nmb, 511 * nmb, 512 * nmb, 513 * nmb, 65280 * nmb] + [int(x) for x in rng.integers(0, 65281 * nmb, 200)]
+            for s in sums:
+                for idr, hist in ((1, 0), (0, 0), (0, 1)):
+                    assert hc.hc_rc_qp(base, idr, hist, s, nmb) == L.orc_rc_qp(base, idr, hist, s, nmb), (base, nmb, s, idr, hist)
+    assert [L.orc_rc_qp(20, 0, 1, c, 1) for c in (256, 512, 1024, 2048)] == [17, 20, 22, 24]   # 2.4 QP per octave, floor
+    assert L.orc_rc_qp(20, 1, 0, 0, 1) == 17 and L.orc_rc_qp(13, 1, 0, 0, 1) == 12 and L.orc_rc_qp(50, 0, 1, 65280, 1) == 51
+    for qp in range(12, 52):
+        assert hc.hc_make_qparams_matches(qp) == 1, qp

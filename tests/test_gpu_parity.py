@@ -431,7 +431,8 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
     data = open(mp4, "rb").read()
     t = read_track(data)
     assert t["timescale"] == 24 and t["stts"] == [(n, 1)] and t["stss"] == [1, 4, 7] and (t["width"], t["height"]) == (w, h)
-    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4)
+    # the C driver opens the encoder as the reference does: X264_RC_CRF (av_encode.c:400-401) = spec/CODEC.md section 1a
+    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True)
     dec = orc.Decoder()
     got = samples_of(data, t)
     for k, f in enumerate(frames):
@@ -581,7 +582,7 @@ def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path)
     assert pct == sorted(pct) and pct[-1] <= 100.0 and pct[-1] > 50.0
     t = read_track(open(mp4, "rb").read())
     assert len(t["stsz"]) == 9 and t["stss"] == [1, 6] and t["timescale"] == 25
-    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4)
+    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True)
     got = samples_of(open(mp4, "rb").read(), t)
     for k in range(9):
         ref = enc.encode(*frames[k])
@@ -590,3 +591,55 @@ def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path)
     # -s: silent, no progress line
     r = run_on_terminal([tool, "-s", "-l", "3", y4m, mp4])
     assert r.returncode == 0 and "video:" not in r.stdout and "silent: 1" in r.stdout
+
+
+def _varied_clip(w, h, n, seed):
+    """Complexity that moves: smooth panning texture, then frames with fresh noise mixed in, then a still picture."""
+    rng = np.random.default_rng(seed)
+    base = noise_frames(w, h, n, seed=seed)
+    out = []
+    for t, (y, u, v) in enumerate(base):
+        if n // 3 <= t < 2 * n // 3:
+            amp = 10 * (t - n // 3 + 1)
+            y = np.clip(y.astype(np.int32) + rng.integers(-amp, amp + 1, y.shape), 0, 255).astype(np.uint8)
+        elif t >= 2 * n // 3:
+            y, u, v = base[2 * n // 3]
+        out.append((y, u, v))
+    return out
+
+
+@pytest.mark.parametrize("w,h,crf,slices,keyint,n,gop_batch", [
+    (352, 288, 24, 4, 6, 18, 1),       # streaming
+    (352, 288, 20, 4, 6, 24, 2),       # two GOPs in lock-step: per-item QPs differ within a launch; partial last unit
+    (176, 144, 13, 2, 4, 9, 1),        # IDR QP clipped at 12
+    (1920, 1080, 26, 8, 3, 5, 1),      # config 2 geometry
+])
+def test_crf_rate_control_matches_oracle(venc, orc, w, h, crf, slices, keyint, n, gop_batch):
+    """X264_RC_CRF -- what the reference asks for (av_encode.c:400-401) -- as spec/CODEC.md section 1a defines it: IDR
+    pictures at base - 3, P pictures at base + delta from the previous picture's SAD sum, decided on the GPU (every block
+    of the search derives the QP alike; k_me_fix corrects the sum for the macroblocks it redoes), slice_qp_delta in every
+    slice header.  Stream equal to the oracle's, picture QPs really move, own decoder follows."""
+    frames = _varied_clip(w, h, n, seed=crf)
+    kw = dict(slices=slices, keyint=keyint, fps=(30, 1), sar=(1, 1), crf=crf, gop_batch=gop_batch)
+    if gop_batch == 1:
+        kw["tune"] = "zerolatency"
+    got = _x264_stream(venc, frames, w, h, **kw)
+    enc = orc.Encoder(w, h, qp=crf, n_slices=slices, keyint=keyint, fps=(30, 1), sar=(1, 1), threads=8, rc=True)
+    dec = orc.Decoder()
+    qps = []
+    for t, f in enumerate(frames):
+        ref = enc.encode(*f)
+        qps.append(enc.picture_qp())
+        assert got[t].payload == ref.data, "frame %d (oracle QP %d): %d vs %d bytes" % (t, qps[-1], len(got[t].payload), len(ref.data))
+        assert dec.decode(got[t].payload) == 1
+        assert np.array_equal(dec.planes()[0], enc.recon()[0])
+    assert qps[0] == max(12, crf - 3) and qps[1] == crf
+    if n >= 9 and w < 1000:
+        assert len(set(q for t, q in enumerate(qps) if t % keyint >= 2)) >= 2, qps   # the P pictures' QP follows the content
+
+
+def test_rate_control_needs_the_whole_picture(venc):
+    e = venc.Engine(176, 144, qp=30, n_slices=3, max_items=1, in_slots=2, out_slots=2, rc=True)
+    with pytest.raises(venc.VencError):
+        e.set_band(0, 2)
+    e.close()

@@ -48,7 +48,7 @@ def build(verbose=False):
 # ----------------------------------------------------------------------------- C-ABI structs
 class VencConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "max_items", "in_slots", "out_slots",
-                                       "device")]
+                                       "device", "rc_mode")]
 
 
 class VencSlice(C.Structure):
@@ -334,10 +334,11 @@ def synth_frame(width, height, frame_index, seed=0x1234ABCD):
 class Engine:
     """One encoder context on one GPU: frame slots in, slice RBSPs out."""
 
-    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None):
-        """lib: a library bound with bind_hip() instead of the product library (tests load the legacy build this way)."""
+    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None, rc=False):
+        """lib: a library bound with bind_hip() instead of the product library (tests load the legacy build this way).
+        rc: picture QP by spec/CODEC.md section 1a (qp = the base) instead of fixed QP."""
         self.L = lib if lib is not None else hip_lib()
-        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device)
+        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)))
         h = C.c_void_p()
         rc = self.L.venc_open(C.byref(self.cfg), C.byref(h))
         if rc != 0:

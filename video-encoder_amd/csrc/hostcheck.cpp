@@ -36,6 +36,16 @@ int hc_block_all_zero(const int *w, int qp, int first) {
     return m[0] <= 2u * (unsigned)q.zt_inter[0] && m[1] <= 2u * (unsigned)q.zt_inter[1] && m[2] <= 2u * (unsigned)q.zt_inter[2];
 }
 int hc_chroma_qp(int qp) { return qp < 30 ? qp : venc_qpc_hi[qp - 30]; }
+int hc_rc_qp(int base, int is_idr, int have_history, unsigned long long sum, int nmb) { return venc_rc_qp(base, is_idr, have_history, sum, nmb); }
+/* 1 iff the device-side construction of a QP's quantiser constants equals the host's */
+int hc_make_qparams_matches(int qp) {
+    venc_qparams a, b;
+    memset(&a, 0, sizeof(a));
+    memset(&b, 0, sizeof(b));
+    hc_fill_qparams(&a, qp);
+    venc_make_qparams(qp, &b);
+    return memcmp(&a, &b, sizeof(a)) == 0 && venc_chroma_qp(qp) == hc_chroma_qp(qp);
+}
 
 void hc_fdct4(const int *x, int *w) { venc_fdct4(x, w); }
 void hc_idct4(const int *d, int *r) { venc_idct4(d, r); }

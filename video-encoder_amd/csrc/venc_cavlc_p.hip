@@ -150,7 +150,7 @@ __global__ __launch_bounds__(CAVLC_P_MAX_THREADS) void k_cavlc_p(venc_geom g, ve
         n_slots = (!skipped && cbpc == 2) ? 4 : 0;
     }
     if (unit == 0) {
-        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
+        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item, B);
         const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
         if (!skipped || mb == slice_last) {
             const uint32_t run = skip_run_before(mask, mb, srow * g.mbw);

@@ -126,6 +126,45 @@ VENC_DEV int venc_quant_chroma_dc(int y, const venc_qparams *q, int intra) {
 }
 VENC_DEV int venc_dequant_chroma_dc(int f, const venc_qparams *q) { return (VENC_MUL24(f, 16 * q->v[0]) << q->per) >> 5; } /* |f| < 2^18 */
 
+VENC_DEV int venc_ilog2(uint32_t v);
+/* ---------------------------------------------------------------- rate control (spec/CODEC.md section 1a)
+ * Picture QP under X264_RC_CRF: IDR base - 3; first P picture of a GOP base; other P pictures base + delta from the mean
+ * best SAD per macroblock of the previous picture, 2.4 QP per octave around a mean SAD of 512.  Integer, identical on
+ * every lane / block that evaluates it. */
+VENC_DEV int venc_rc_ilog2q(uint32_t c) { /* quarter octaves: 4 floor(log2 c) + the two bits below the leading one */
+    if (c < 1u) c = 1u;
+    const int k = venc_ilog2(c);
+    const int frac = k >= 2 ? (int)((c >> (k - 2)) & 3u) : (int)((c << (2 - k)) & 3u);
+    return 4 * k + frac;
+}
+VENC_DEV int venc_rc_qp(int base_qp, int is_idr, int have_history, unsigned long long prev_sad_sum, int nmb) {
+    int qp = base_qp;
+    if (is_idr)
+        qp = base_qp - 3;
+    else if (have_history) {
+        const uint32_t c = (uint32_t)(prev_sad_sum / (unsigned long long)(nmb > 0 ? nmb : 1));
+        const int num = 3 * (venc_rc_ilog2q(c) - 36);
+        int delta = num >= 0 ? num / 5 : -((-num + 4) / 5); /* floor division */
+        delta = delta < -6 ? -6 : delta > 6 ? 6 : delta;
+        qp = base_qp + delta;
+    }
+    return qp < 12 ? 12 : qp > 51 ? 51 : qp;
+}
+/* quantiser constants of a QP from the tables (what the host computes once per encoder at fixed QP) */
+VENC_DEV void venc_make_qparams(int qp, venc_qparams *q) {
+    const int per = qp / 6, rem = qp - 6 * per;
+    q->per = per;
+    q->qbits = 15 + per;
+    for (int k = 0; k < 3; k++) {
+        q->mf[k] = venc_mf[rem * 3 + k];
+        q->v[k] = venc_v[rem * 3 + k];
+    }
+    q->f_intra = (1 << q->qbits) / 3;
+    q->f_inter = (1 << q->qbits) / 6;
+    for (int k = 0; k < 3; k++) q->zt_inter[k] = ((1 << q->qbits) - q->f_inter - 1) / q->mf[k];
+}
+VENC_DEV int venc_chroma_qp(int qp) { return qp < 30 ? qp : venc_qpc_hi[qp - 30]; }
+
 /* ---------------------------------------------------------------- bit sink */
 /* MSB-first 32-bit words into lane-private memory */
 typedef struct {

@@ -84,6 +84,12 @@ struct venc_ctx {
     int chroma_pending;               /* ev_chroma recorded and not yet waited for by the main stream */
     int fuse_luma;                    /* 1 (default): luma transform inside k_me_pool / k_me_fix, chroma on stream 2; VENC_FUSE=0: k_inter_fused on the main chain */
     int fix_phase;                    /* which set of fix counters the next P step fills */
+    /* rate control (cfg.rc_mode; spec/CODEC.md section 1a) */
+    venc_geom g_idr;                  /* geometry with the quantiser constants of IDR pictures (base - 3) */
+    unsigned long long *d_sad_sum;    /* [3][G] per-item sums of best SADs, rotating between P steps */
+    int *d_qp_ring;                   /* [VENC_RING][G] QP each (step, item) was coded at */
+    int rc_phase;                     /* set the next P step adds to */
+    int last_step_p;                  /* the previous step was a P step */
     hipEvent_t ev_side[VENC_RING];    /* per ring slot: the entropy kernels that read the slot's motion vectors, levels and records are done */
     long long side_step[VENC_RING];  /* step whose entropy batch recorded ev_side[slot] (-1: none) */
     /* the open entropy batch: steps whose main chain is enqueued and whose entropy chain is not */
@@ -269,6 +275,8 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.me_cnt);
     (void)hipFree(c->b.stamps);
     (void)hipFree(c->b.fix_count);
+    (void)hipFree(c->d_sad_sum);
+    (void)hipFree(c->d_qp_ring);
     (void)hipFree(c->b.intra_rec);
     (void)hipFree(c->b.intra_d0);
     (void)hipFree(c->b.fix_list);
@@ -338,6 +346,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     fill_qparams(&g.ql, cfg->qp);
     fill_qparams(&g.qc, cfg->qp < 30 ? cfg->qp : h_qpc_hi[cfg->qp - 30]);
     c->cfg.n_slices = g.n_slices;
+    c->g_idr = g;
     g.slice_base = g.mbh / g.n_slices;
     g.slice_rem = g.mbh % g.n_slices;
 
@@ -531,6 +540,23 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
+    if (cfg->rc_mode) {
+        if (c->me_mode != 0 || c->inter_legacy || c->intra_legacy) {
+            SET_ERR("venc_open: rate control needs the shipped kernels (not the legacy test variants)");
+            venc_close(c);
+            return -1;
+        }
+        int qi = cfg->qp - 3;
+        qi = qi < 12 ? 12 : qi;
+        c->g_idr = g;
+        c->g_idr.qp = qi;
+        fill_qparams(&c->g_idr.ql, qi);
+        fill_qparams(&c->g_idr.qc, qi < 30 ? qi : h_qpc_hi[qi - 30]);
+        OPEN_OK(hipMalloc(&c->d_sad_sum, 3 * G * sizeof(unsigned long long)));
+        OPEN_OK(hipMemset(c->d_sad_sum, 0, 3 * G * sizeof(unsigned long long)));
+        OPEN_OK(hipMalloc(&c->d_qp_ring, VENC_RING * G * sizeof(int)));
+        OPEN_OK(hipMemset(c->d_qp_ring, 0, VENC_RING * G * sizeof(int)));
+    }
     OPEN_OK(hipMalloc(&b.fix_count, 2 * G * 4));
     OPEN_OK(hipMalloc(&b.intra_rec, G * nmb * INTRA_REC_DWORDS * 4));
     OPEN_OK(hipMalloc(&b.intra_d0, G * nmb * 32 * 4));
@@ -694,6 +720,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.frame_num = frame_num;
     S.parity = c->parity;
     S.ref = c->rec_last;
+    S.rc_mode = c->cfg.rc_mode ? 1 : 0;
+    S.qp_base = c->cfg.qp;
+    S.qp_idr = c->g_idr.qp;
+    S.rc_history = !is_idr && c->last_step_p;
     S.me_stop = c->me_stop;
     S.slice0 = c->band_s0;
     S.slice1 = c->band_s1;
@@ -727,6 +757,16 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     b.mvsad_prev = c->b.mvsad + (size_t)rs_prev * GN;
     b.levels = c->b.levels + (size_t)rs * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
+    if (c->cfg.rc_mode) {
+        const size_t G_ = (size_t)c->b.max_items;
+        b.qp_cur = c->d_qp_ring + (size_t)rs * G_;
+        if (!is_idr) {
+            b.sad_prev = c->d_sad_sum + (size_t)((c->rc_phase + 2) % 3) * G_;
+            b.sad_cur = c->d_sad_sum + (size_t)c->rc_phase * G_;
+            b.sad_next = c->d_sad_sum + (size_t)((c->rc_phase + 1) % 3) * G_;
+            c->rc_phase = (c->rc_phase + 1) % 3;
+        }
+    }
     hipStream_t s1 = c->stream;
     bool chroma_deferred = false;
     /* an open entropy batch takes this step only if it continues it: same kind of picture (P), same items, same band,
@@ -778,9 +818,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
 #endif
         {
             /* transform off the dependency chain, DC chain, reconstruction (venc_intra2.hip) */
-            hipLaunchKernelGGL(k_intra_fwd, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
-            hipLaunchKernelGGL(k_intra_dc, dim3(band_slices, 1, n_items), dim3(1024), 0, s1, g, b, S, c->intra_cw);
-            hipLaunchKernelGGL(k_intra_rec, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, g, b, S);
+            const venc_geom &gi = c->cfg.rc_mode ? c->g_idr : g; /* IDR pictures under rate control: their own quantiser constants */
+            hipLaunchKernelGGL(k_intra_fwd, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, gi, b, S);
+            hipLaunchKernelGGL(k_intra_dc, dim3(band_slices, 1, n_items), dim3(1024), 0, s1, gi, b, S, c->intra_cw);
+            hipLaunchKernelGGL(k_intra_rec, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, gi, b, S);
         }
         prof_end(c, s1);
         if (intra_async) {
@@ -877,6 +918,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     }
     c->rec_last = c->parity;
     c->parity = (c->parity + 1) % VENC_RECON;
+    c->last_step_p = !is_idr;
     c->step_no++;
     c->steps_done++;
     /* closed: I pictures (their own kernel), ragged steps, the last slot of the group, a full batch */
@@ -901,6 +943,7 @@ static int entropy_flush(venc_ctx *c) {
     b.mvsad = c->b.mvsad + (size_t)rs0 * GN;
     b.levels = c->b.levels + (size_t)rs0 * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs0 * GN;
+    if (c->cfg.rc_mode) b.qp_cur = c->d_qp_ring + (size_t)rs0 * c->b.max_items;
     b.unit_count = c->b.unit_count + (size_t)c->unit_phase * c->b.vcap * VENC_COUNTER_STRIDE;
     b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.vcap * VENC_COUNTER_STRIDE;
     if (!is_idr) c->unit_phase ^= 1;
@@ -925,6 +968,7 @@ static int entropy_flush(venc_ctx *c) {
             bk.mvsad = c->b.mvsad + (size_t)rsk * GN;
             bk.levels = c->b.levels + (size_t)rsk * GN * VENC_MB_COEFS;
             bk.mbinfo = c->b.mbinfo + (size_t)rsk * GN;
+            if (c->cfg.rc_mode) bk.qp_cur = c->d_qp_ring + (size_t)rsk * c->b.max_items;
             prof_begin(c, KID_INTER, s2);
             hipLaunchKernelGGL(k_inter_fused, dim3((band_mbs + 31) / 32, 1, c->eb_step[k].n_items), dim3(256), 0, s2, g, bk, c->eb_step[k], 0);
             prof_end(c, s2);
@@ -978,6 +1022,10 @@ extern "C" int venc_set_band(venc_ctx *c, int slice_first, int slice_count) {
     if (slice_first == 0 && slice_count == 0) slice_count = c->g.n_slices;
     if (slice_first < 0 || slice_count < 1 || slice_first + slice_count > c->g.n_slices) {
         SET_ERR("venc_set_band: slices [%d, %d) outside 0..%d", slice_first, slice_first + slice_count, c->g.n_slices);
+        return -1;
+    }
+    if (c->cfg.rc_mode && slice_count != c->g.n_slices) {
+        SET_ERR("venc_set_band: rate control needs the whole picture (its SAD sum spans all slices)");
         return -1;
     }
     if ((c->me_mode == 1 || c->inter_legacy) && slice_count != c->g.n_slices) {

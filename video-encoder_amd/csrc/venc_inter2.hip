@@ -126,8 +126,21 @@ DEVFN void unpack4(uint32_t v, int *o) {
 /* residual, transform, quantisation, reconstruction and stores of one luma 4x4 block per lane from its current rows cq[]
  * and predicted rows pq[] (four samples per dword): 16 lanes per macroblock, lane & 15 = luma4x4BlkIdx, lane & 48 = the
  * wave's group of 16; every lane of the wave calls this (ballots), `valid` guards the stores */
+/* quantiser constants of this step's pictures: the encoder's fixed ones, or under rate control those of the QP the search
+ * chose for (step, item) (B.qp_cur, written by the first tile of k_me_pool before any kernel that calls this runs) */
+DEVFN void step_qparams(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, venc_qparams &ql, venc_qparams &qc) {
+    if (S.rc_mode) {
+        const int qp = B.qp_cur[item];
+        venc_make_qparams(qp, &ql);
+        venc_make_qparams(venc_chroma_qp(qp), &qc);
+    } else {
+        ql = g.ql;
+        qc = g.qc;
+    }
+}
+
 DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, const uint32_t cq[4],
-                           const uint32_t pq[4]) {
+                           const uint32_t pq[4], const venc_qparams &ql) {
     const int blk = lane & 15, gbase = lane & 48;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
@@ -143,7 +156,7 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
     }
     venc_fdct4(res, w);
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
-    if (__ballot(valid && !blk_all_zero<false>(w, g.ql)) == 0ull) {
+    if (__ballot(valid && !blk_all_zero<false>(w, ql)) == 0ull) {
         /* every block of the wave quantises to zero: no levels, the reconstruction is the prediction */
         if (valid) {
             info->nnz[blk_y(blk) * 4 + blk_x(blk)] = 0;
@@ -156,7 +169,7 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
         }
         return;
     }
-    blk_quant_res<false>(w, g.ql, g.ql.f_inter, 0, lv, rr, nnz);
+    blk_quant_res<false>(w, ql, ql.f_inter, 0, lv, rr, nnz);
 #pragma unroll
     for (int y = 0; y < 4; y++) {
         rr[4 * y] = venc_clip_u8(int_add_byte<0>(rr[4 * y], pq[y]));
@@ -183,37 +196,9 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
     }
 }
 
-/* One luma 4x4 block, no cross-lane traffic: residual, transform, quantisation, reconstruction; stores the levels, the
- * block's TotalCoeff and the reconstructed samples.  For the blocks k_me_pool's P5 lists as not all-zero. */
-DEVFN void luma_block_full(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int mb, int blk, const uint32_t cq[4], const uint32_t pq[4]) {
-    const int mx = mb % g.mbw, my = mb / g.mbw;
-    const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
-    int wstride;
-    uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
-    int res[16], w[16], lv[16], rr[16], nnz;
-#pragma unroll
-    for (int y = 0; y < 4; y++) {
-        res[4 * y] = byte_sub_byte<0>(cq[y], pq[y]);
-        res[4 * y + 1] = byte_sub_byte<1>(cq[y], pq[y]);
-        res[4 * y + 2] = byte_sub_byte<2>(cq[y], pq[y]);
-        res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
-    }
-    venc_fdct4(res, w);
-    blk_quant_res<false>(w, g.ql, g.ql.f_inter, 0, lv, rr, nnz);
-#pragma unroll
-    for (int y = 0; y < 4; y++) {
-        rr[4 * y] = venc_clip_u8(int_add_byte<0>(rr[4 * y], pq[y]));
-        rr[4 * y + 1] = venc_clip_u8(int_add_byte<1>(rr[4 * y + 1], pq[y]));
-        rr[4 * y + 2] = venc_clip_u8(int_add_byte<2>(rr[4 * y + 2], pq[y]));
-        rr[4 * y + 3] = venc_clip_u8(int_add_byte<3>(rr[4 * y + 3], pq[y]));
-    }
-    store_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + blk * 16, lv);
-    (B.mbinfo + (size_t)item * g.nmb + mb)->nnz[blk_y(blk) * 4 + blk_x(blk)] = (uint8_t)nnz;
-    store_rec4x4(rec, wstride, px, py, rr);
-}
-
 /* luma transform of macroblock mb with vector (dx, dy), current and predicted samples fetched from memory */
-DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy) {
+DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy,
+                         const venc_qparams &ql) {
     const int blk = lane & 15;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
@@ -240,11 +225,12 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
                     ((uint32_t)row[clampi(x0 + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(x0 + 3, 0, g.cw - 1)] << 24);
         }
     }
-    luma_block_code(g, B, S, item, lane, mb, valid, cq, pq);
+    luma_block_code(g, B, S, item, lane, mb, valid, cq, pq, ql);
 }
 
 /* chroma transform of macroblock mb: 8 lanes, lane & 3 = block, (lane >> 2) & 1 = plane, lane & 56 = group of 8 */
-DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy) {
+DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy,
+                           const venc_qparams &qc) {
     const int k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
@@ -318,22 +304,22 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
         const int v = __shfl(w[0], qbase | qi);
         yc += (__popc(k & qi) & 1) ? -v : v;
     }
-    const int dclv = venc_quant_chroma_dc(yc, &g.qc, 0);
+    const int dclv = venc_quant_chroma_dc(yc, &qc, 0);
     int fc = 0;
 #pragma unroll
     for (int qi = 0; qi < 4; qi++) {
         const int v = __shfl(dclv, qbase | qi);
         fc += (__popc(k & qi) & 1) ? -v : v;
     }
-    const int d0 = venc_dequant_chroma_dc(fc, &g.qc);
-    if (__ballot(valid && !blk_all_zero<true>(w, g.qc)) == 0ull) {
+    const int d0 = venc_dequant_chroma_dc(fc, &qc);
+    if (__ballot(valid && !blk_all_zero<true>(w, qc)) == 0ull) {
         /* no AC level in any block of the wave: the inverse transform of a lone DC is (d0 + 32) >> 6 in every sample */
         const int r0 = (d0 + 32) >> 6;
         nnz = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) lv[i] = 0, rr[i] = venc_clip_u8(p[i] + r0);
     } else {
-        blk_quant_res<true>(w, g.qc, g.qc.f_inter, d0, lv, rr, nnz);
+        blk_quant_res<true>(w, qc, qc.f_inter, d0, lv, rr, nnz);
 #pragma unroll
         for (int i = 0; i < 16; i++) rr[i] = venc_clip_u8(p[i] + rr[i]);
     }
@@ -382,17 +368,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int item = blockIdx.z, tid = threadIdx.x, lane = tid & 63;
     const int bx = blockIdx.x;
     const uint32_t *mvs = B.mvsad + (size_t)item * g.nmb;
+    venc_qparams ql, qc;
+    step_qparams(g, B, S, item, ql, qc);
     if (bx >= n_luma) {
         const int mb_raw = S.mb0 + (bx - n_luma) * 32 + (tid >> 3);
         const bool valid = mb_raw < S.mb1;
         const int mb = valid ? mb_raw : S.mb1 - 1;
         const uint32_t m = mvs[mb];
-        inter_chroma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u));
+        inter_chroma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u), qc);
     } else {
         const int mb_raw = S.mb0 + bx * 16 + (tid >> 4);
         const bool valid = mb_raw < S.mb1;
         const int mb = valid ? mb_raw : S.mb1 - 1;
         const uint32_t m = mvs[mb];
-        inter_luma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u));
+        inter_luma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u), ql);
     }
 }

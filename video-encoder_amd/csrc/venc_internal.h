@@ -82,6 +82,11 @@ typedef struct {
      * ("entropy batch", venc_hip.hip): its grid's item index then runs over (step, item) pairs, v = k * max_items + item,
      * and the per-item fields above and this one are indexed by v.  fnum[v] = frame_num of the step v belongs to. */
     uint8_t fnum[VENC_MAX_ITEMS];
+    /* rate control (spec/CODEC.md section 1a; 0 = fixed QP, the quantiser constants of venc_geom apply) */
+    int rc_mode;
+    int qp_base;    /* pic_init_qp */
+    int qp_idr;     /* QP of IDR pictures under rate control (host-known: base - 3, clipped) */
+    int rc_history; /* P step: the previous picture of every chain was a P picture too (its SAD sum steers this one's QP) */
 } venc_step;
 
 #define VENC_COUNTER_STRIDE 32 /* words between per-item atomic counters: one cache line each */
@@ -123,6 +128,12 @@ typedef struct {
     uint32_t *fix_list;         /* [G][nmb] their indices */
     unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
+    /* rate control: three sets of per-item sums of the best SADs rotate between P steps -- the search of a step reads the
+     * previous step's, adds to its own (k_me_fix corrects it for the macroblocks it redoes) and zeroes the next one's --
+     * and the QP each (step, item) was coded at, in the step ring, for the kernels that run later (chroma, entropy) */
+    const unsigned long long *sad_prev;
+    unsigned long long *sad_cur, *sad_next;
+    int *qp_cur;
     uint8_t *out_hdr;           /* device view of the pinned header pool: per slot venc_out_header + slice table */
     size_t out_hdr_stride;
     uint8_t *out_data;          /* per slot data[]: HBM staging buffer, or the device view of the pinned host pool */

@@ -685,7 +685,7 @@ DEVFN void load_levels(const int16_t *src, int c[16]) {
 }
 
 /* slice_header(), 7.3.3 -- written by the lane that codes the first macroblock of a slice */
-DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int item) {
+DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int item, const venc_bufs &B) {
     venc_bs_ue(bs, (uint32_t)mb);
     venc_bs_ue(bs, S.is_idr ? 7u : 5u);
     venc_bs_ue(bs, 0);
@@ -696,7 +696,8 @@ DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int i
     } else {
         venc_bs_put(bs, 0, 3); /* override, list modification, adaptive marking */
     }
-    venc_bs_se(bs, 0); /* slice_qp_delta */
+    /* slice_qp_delta: 0 at fixed QP; under rate control the picture's QP (spec/CODEC.md section 1a) against pic_init_qp */
+    venc_bs_se(bs, S.rc_mode ? (S.is_idr ? S.qp_idr : B.qp_cur[item]) - S.qp_base : 0);
     venc_bs_ue(bs, 1); /* disable_deblocking_filter_idc */
 }
 
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, first, maxc, nC, s_tab);
     }
     if (l32 == 0 && valid) {
-        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item);
+        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item, B);
         if (i16) {
             venc_bs_ue(&bs, (uint32_t)(1 + 2 + 4 * cbpc + 12 * (cbpl != 0)));
             venc_bs_ue(&bs, 0);

@@ -319,6 +319,8 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
+    venc_qparams qlf, qcf;
+    step_qparams(g, B, S, item, qlf, qcf);
     const int dy0 = wave * FIX_NDY;          /* first dy index of this wave */
     const int dxi = lane < 33 ? lane : 32;   /* lanes 33..63 repeat column 32 and are ignored */
     /* the ranks of this lane's candidates do not depend on the macroblock: fetched before anything else, used last */
@@ -399,6 +401,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
         for (int k = 1; k < FIX_WAVES; k++) best = min(best, s_best[k]);
         if (mine == best) {
             const int dx = dxi - 16, dy = dy0 + mine_k - 16;
+            if (S.rc_mode) { /* the picture's SAD sum holds what k_me_pool found for this macroblock: correct it */
+                const uint32_t old = B.mvsad[(size_t)item * g.nmb + mb] >> 16;
+                atomicAdd(&B.sad_cur[item], (unsigned long long)(long long)((int)(best >> 11) - (int)old));
+            }
             B.mvsad[(size_t)item * g.nmb + mb] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
             s_mv[0] = dxi, s_mv[1] = dy0 + mine_k; /* window position of the winner */
         }
@@ -417,10 +423,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
                     cq[y] = s_cur[(by + y) * 4 + (bx >> 2)];
                     pq[y] = __builtin_amdgcn_alignbyte(wp[y * FIX_WD + 1], wp[y * FIX_WD], sh);
                 }
-                luma_block_code(g, B, S, item, lane, mb, lane < 16, cq, pq);
+                luma_block_code(g, B, S, item, lane, mb, lane < 16, cq, pq, qlf);
             }
             if (fuse_luma > 1 && tid >= 64 && tid < 128) /* its chroma transform: lanes 0-7 of wave 1 */
-                inter_chroma_mb(g, B, S, item, lane, mb, lane < 8, s_mv[0] - 16, s_mv[1] - 16);
+                inter_chroma_mb(g, B, S, item, lane, mb, lane < 8, s_mv[0] - 16, s_mv[1] - 16, qcf);
         }
     }
 }

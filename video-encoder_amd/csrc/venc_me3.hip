@@ -119,7 +119,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const int kx = (int)(blockIdx.x >> 3);
     const int tile = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
     if (tile >= tiles_x * tiles_y) return;
-    if (tile == 0 && threadIdx.x == 0) B.fix_count_next[item] = 0; /* the other counter: the next P step's search fills it, nobody reads it now */
+    if (tile == 0 && threadIdx.x == 0) {
+        B.fix_count_next[item] = 0; /* the other counter: the next P step's search fills it, nobody reads it now */
+        if (S.rc_mode) {            /* rate control: this picture's QP for the kernels that run later; the next step's SAD sum starts at zero */
+            B.qp_cur[item] = venc_rc_qp(S.qp_base, 0, S.rc_history, B.sad_prev[item], g.nmb);
+            B.sad_next[item] = 0ull;
+        }
+    }
     /* tx_magic = ceil(2^32 / tiles_x), exact for these sizes; 0 stands for tiles_x == 1 (2^32 does not fit) */
     const int ty = tx_magic ? (int)__umulhi((uint32_t)tile, tx_magic) : tile, tx = tile - ty * tiles_x;
     const int x0 = tx * T2_MBX * 16, y0 = (S.row0 + ty * T2_MBY) * 16;
@@ -442,6 +448,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * dequantisation, inverse transform, reconstruction, levels (venc_inter2.hip luma_block_code).  16 macroblocks x 16
      * blocks = the lanes of waves 0-3; macroblocks listed for k_me_fix are left to it.  The transform no longer re-reads
      * the two luma planes from memory and costs the main chain no launch of its own. ---- */
+    /* the pictures' quantiser constants: fixed, or from the QP every block derives alike from the previous picture's SAD
+     * sum (spec/CODEC.md section 1a) */
+    venc_qparams ql5 = g.ql, qc5 = g.qc;
+    if (S.rc_mode) {
+        const int qp5 = venc_rc_qp(S.qp_base, 0, S.rc_history, B.sad_prev[item], g.nmb);
+        venc_make_qparams(qp5, &ql5);
+        venc_make_qparams(venc_chroma_qp(qp5), &qc5);
+        if (threadIdx.x >= 448) { /* wave 7 has nothing to do in P5: this tile's share of the picture's SAD sum, one atomic per block */
+            const int l7 = threadIdx.x - 448;
+            uint32_t sad = 0;
+            if (l7 < T2_MBX * T2_MBY) {
+                const int mx7 = tx * T2_MBX + (l7 & (T2_MBX - 1)), my7 = S.row0 + ty * T2_MBY + (l7 >> 3);
+                if (mx7 < g.mbw && my7 < S.row1) sad = (uint32_t)(s_best[l7] >> 22);
+            }
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(sad), 63);
+            if (l7 == 0 && tot) atomicAdd(&B.sad_cur[item], (unsigned long long)tot);
+        }
+    }
     if (fuse_luma > 1 && threadIdx.x >= 256 && threadIdx.x < 384) {
         /* ... and the chroma transform of the same macroblocks on waves 4 and 5, which would otherwise have left: 8 lanes
          * per macroblock, samples from memory (the chroma planes are not in LDS), venc_inter2.hip inter_chroma_mb.  No chroma
@@ -450,7 +474,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
         const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] == 0u;
         const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
-        inter_chroma_mb(g, B, S, item, t6 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, (int)bcx - 16, (int)bcy - 16);
+        inter_chroma_mb(g, B, S, item, t6 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, (int)bcx - 16, (int)bcy - 16, qc5);
     }
     if (fuse_luma && threadIdx.x < 256) {
         const int t5 = threadIdx.x, m = t5 >> 4, blk = t5 & 15;
@@ -469,6 +493,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             cq[y] = cp[y * T3_CW];
             pq[y] = __builtin_amdgcn_alignbyte(wp[y * T2_WD + 1], wp[y * T2_WD], sh);
         }
-        luma_block_code(g, B, S, item, t5 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, cq, pq);
+        luma_block_code(g, B, S, item, t5 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, cq, pq, ql5);
     }
 }

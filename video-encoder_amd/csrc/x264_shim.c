@@ -202,6 +202,10 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     cfg.in_slots = h->pool;
     cfg.out_slots = h->pool;
     cfg.device = param->hip.i_device;
+    /* X264_RC_CRF (what the reference asks for, av_encode.c:400-401): the rate factor is the base QP and every picture's QP
+     * follows spec/CODEC.md section 1a -- a frame-level approximation of libx264's CRF, decided on the GPU.  Slice-band
+     * encoders keep the fixed QP (the rule needs the whole picture's SAD sum). */
+    cfg.rc_mode = param->rc.i_rc_method == X264_RC_CRF && param->hip.i_slice_count <= 0 && param->hip.i_slice_first <= 0 && param->hip.i_rccl_world <= 0;
     if (venc_open(&cfg, &h->ctx) != 0) {
         fprintf(stderr, "x264 [venc]: %s\n", venc_last_error());
         free(h);
