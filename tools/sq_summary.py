@@ -17,7 +17,7 @@ dur = collections.defaultdict(lambda: [0.0, 0])
 for sub in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT"):
     f = glob.glob("%s/%s/*/*counter_collection.csv" % (d, sub))[0]
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         a = acc[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"])
         a[1] += 1

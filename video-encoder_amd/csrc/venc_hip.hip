@@ -858,7 +858,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             const int gx = c->me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
             /* (VENC_ME_LDS_PAD=bytes of unused dynamic LDS per block: an experiment that holds the search at two blocks per CU) */
             static const int lds_pad = getenv("VENC_ME_LDS_PAD") ? atoi(getenv("VENC_ME_LDS_PAD")) : 0;
-            hipLaunchKernelGGL(k_me_pool, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            if (c->cfg.rc_mode)
+                hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            else
+                hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
         }
         prof_end(c, s1);
         const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */

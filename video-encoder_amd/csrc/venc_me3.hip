@@ -80,6 +80,9 @@ DEVFN uint32_t me3_quarter_sad(const uint32_t *s_win, const uint32_t *s_cur, int
     return a;
 }
 
+/* RC: the rate-control variant (spec/CODEC.md section 1a) -- a template parameter, so that the fixed-QP kernel carries neither
+ * its branches nor a second set of quantiser constants in scalar registers */
+template <bool RC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_me_pool(venc_geom g, venc_bufs B, venc_step S, int tiles_x, int tiles_y, uint32_t tx_magic, int xcd_runs, int fuse_luma) {
     __shared__ __attribute__((aligned(16))) uint32_t s_win[T2_WR * T2_WD];
     __shared__ __attribute__((aligned(16))) uint32_t s_cur[T2_MBY * 16 * T3_CW];
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     if (tile >= tiles_x * tiles_y) return;
     if (tile == 0 && threadIdx.x == 0) {
         B.fix_count_next[item] = 0; /* the other counter: the next P step's search fills it, nobody reads it now */
-        if (S.rc_mode) {            /* rate control: this picture's QP for the kernels that run later; the next step's SAD sum starts at zero */
+        if (RC) {                   /* rate control: this picture's QP for the kernels that run later; the next step's SAD sum starts at zero */
             B.qp_cur[item] = venc_rc_qp(S.qp_base, 0, S.rc_history, B.sad_prev[item], g.nmb);
             B.sad_next[item] = 0ull;
         }
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     /* the pictures' quantiser constants: fixed, or from the QP every block derives alike from the previous picture's SAD
      * sum (spec/CODEC.md section 1a) */
     venc_qparams ql5 = g.ql, qc5 = g.qc;
-    if (S.rc_mode) {
+    if (RC) {
         const int qp5 = venc_rc_qp(S.qp_base, 0, S.rc_history, B.sad_prev[item], g.nmb);
         venc_make_qparams(qp5, &ql5);
         venc_make_qparams(venc_chroma_qp(qp5), &qc5);
