@@ -48,6 +48,9 @@ typedef struct {
     int rc_mode;       /* 0: every picture at qp; 1: picture QP chosen on the GPU from the previous picture's motion search
                           (spec/CODEC.md section 1a: the frame-level approximation of libx264's CRF; qp = the rate factor,
                           IDR pictures qp - 3, P pictures qp +- up to 6).  Whole-picture engines only. */
+    int intra_modes;   /* 0: Intra16x16 with DC prediction only (the three-kernel I path); 1: vertical / horizontal / DC chosen
+                          per macroblock by SAD (spec/CODEC.md section 3; one wavefront kernel, ~3x the I-step time, hidden
+                          behind the previous unit's P steps) */
 } venc_config;
 
 /* Per-slice record of an encoded frame (raw RBSP: slice header + slice data +

@@ -106,6 +106,9 @@ typedef struct x264_param_t {
          * ncclAllGather).  pf_exchange, when set, takes precedence. */
         int i_rccl_world, i_rccl_rank, i_halo_rows;
         unsigned char rccl_id[128];
+        /* Intra16x16 prediction of I pictures: 1 (x264_param_default_preset's default, like libx264's presets) = vertical /
+         * horizontal / DC chosen per macroblock by SAD; 0 = DC only (the codec definition of round 1, what bench.py measures) */
+        int i_intra_modes;
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;

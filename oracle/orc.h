@@ -53,6 +53,7 @@ typedef struct {
     int idr_base;        /* index of the first closed GOP (idr_pic_id = (idr_base + n) & 1): lets a
                             GOP-sharded run reproduce the single-encoder stream */
     int rc_mode;         /* 0: fixed QP; 1: picture QP by spec/CODEC.md section 1a (qp = the base QP) */
+    int intra_modes;     /* 0: Intra16x16 DC prediction only; 1: vertical / horizontal / DC chosen by SAD (spec/CODEC.md section 3) */
 } orc_params;
 
 typedef struct {

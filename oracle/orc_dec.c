@@ -447,7 +447,7 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             if (st == 0) FAIL(d, "intra MB in P slice unsupported");
             if (t < 1 || t > 24) FAIL(d, "mb_type %d unsupported in I slice", t);
             int pm = (t - 1) & 3, cbpc = ((t - 1) >> 2) % 3, acf = (t - 1) >= 12;
-            if (pm != 2) FAIL(d, "Intra16x16 pred mode %d unsupported", pm);
+            if (pm == 3) FAIL(d, "Intra16x16 plane prediction unsupported");
             if (br_ue(b) != 0) FAIL(d, "intra chroma pred mode unsupported");
             qp += br_se(b);
             int16_t dcl[16], ac[16][16];
@@ -469,8 +469,16 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             if (aL)
                 for (int y = 0; y < 16; y++) sum += dst[(size_t)y * d->cw - 1];
             dcp = aT && aL ? (sum + 16) >> 5 : (aT || aL) ? (sum + 8) >> 4 : 128;
-            uint8_t predl[16];
-            memset(predl, dcp, 16);
+            /* the 16x16 predictor (8.3.3.1-8.3.3.3): vertical = the row above, horizontal = the column to the left, DC */
+            uint8_t pred16[256];
+            if (pm == 0) {
+                if (!aT) FAIL(d, "Intra16x16 vertical prediction without a macroblock above (mb %d)", mb);
+                for (int y = 0; y < 16; y++) memcpy(pred16 + 16 * y, dst - (ptrdiff_t)d->cw, 16);
+            } else if (pm == 1) {
+                if (!aL) FAIL(d, "Intra16x16 horizontal prediction without a macroblock to the left (mb %d)", mb);
+                for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, dst[(size_t)y * d->cw - 1], 16);
+            } else
+                memset(pred16, dcp, 256);
             /* luma DC: inverse zig-zag, 4x4 Hadamard, scaling (8.5.10) */
             int c[4][4], f[4][4], tt[4][4];
             for (int k = 0; k < 16; k++) c[orc_zigzag4x4[k] >> 2][orc_zigzag4x4[k] & 3] = dcl[k];
@@ -493,10 +501,9 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
                 int ls = level_scale(qp, 0, 0);
                 dd[0][0] = qp >= 36 ? (f[by][bx] * ls) << (qp / 6 - 6) : (f[by][bx] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
                 uint8_t pr[16];
-                memset(pr, dcp, 16);
+                for (int y = 0; y < 4; y++) memcpy(pr + 4 * y, pred16 + 16 * (4 * by + y) + 4 * bx, 4);
                 inv_transform_add(dst + (size_t)(4 * by) * d->cw + 4 * bx, d->cw, pr, 4, dd);
             }
-            (void)predl;
             /* chroma DC prediction */
             uint8_t pred[2][64];
             for (int p = 0; p < 2; p++) {

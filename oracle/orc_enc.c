@@ -323,7 +323,7 @@ struct orc_enc {
     int16_t *levels;
     uint32_t *mb_bits;
     uint8_t *nnz_l, *nnz_cb, *nnz_cr;
-    uint8_t *mb_cbp, *mb_i16flags;
+    uint8_t *mb_cbp, *mb_i16flags, *mb_i16mode;
     uint16_t rank[33 * 33];
     uint8_t cbp_to_code[48];
     uint8_t **slice_buf;
@@ -393,6 +393,7 @@ orc_enc *orc_enc_open(const orc_params *p) {
     e->nnz_cr = (uint8_t *)calloc((size_t)nmb * 4, 1);
     e->mb_cbp = (uint8_t *)calloc((size_t)nmb, 1);
     e->mb_i16flags = (uint8_t *)calloc((size_t)nmb, 1);
+    e->mb_i16mode = (uint8_t *)calloc((size_t)nmb, 1);
     for (int dy = -16; dy <= 16; dy++)
         for (int dx = -16; dx <= 16; dx++) e->rank[(dy + 16) * 33 + dx + 16] = (uint16_t)orc_me_rank(dx, dy);
     for (int i = 0; i < 48; i++) e->cbp_to_code[orc_golomb_to_inter_cbp[i]] = (uint8_t)i;
@@ -434,6 +435,7 @@ void orc_enc_close(orc_enc *e) {
     free(e->nnz_cr);
     free(e->mb_cbp);
     free(e->mb_i16flags);
+    free(e->mb_i16mode);
     free(e);
 }
 
@@ -590,13 +592,43 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
         dcp = (sum + 8) >> 4;
     else
         dcp = 128;
+    /* the 16x16 predictor: DC, or (intra_modes) whichever of vertical (0), horizontal (1), DC (2) has the smallest SAD
+     * against the source, the smaller mode number on ties; vertical needs the macroblock above, horizontal the one to the
+     * left, inside the slice (8.3.3) */
+    uint8_t pred16[256];
+    int mode = 2;
+    memset(pred16, dcp, 256);
+    if (e->p.intra_modes) {
+        long sad[3] = {-1, -1, 0};
+        for (int y = 0; y < 16; y++)
+            for (int x = 0; x < 16; x++) sad[2] += abs((int)cur[(size_t)y * e->cw + x] - dcp);
+        if (avail_t) {
+            sad[0] = 0;
+            for (int y = 0; y < 16; y++)
+                for (int x = 0; x < 16; x++) sad[0] += abs((int)cur[(size_t)y * e->cw + x] - (int)rec[-(ptrdiff_t)e->cw + x]);
+        }
+        if (avail_l) {
+            sad[1] = 0;
+            for (int y = 0; y < 16; y++)
+                for (int x = 0; x < 16; x++) sad[1] += abs((int)cur[(size_t)y * e->cw + x] - (int)rec[(size_t)y * e->cw - 1]);
+        }
+        long best = sad[2];
+        for (int m = 1; m >= 0; m--)
+            if (sad[m] >= 0 && sad[m] <= best) best = sad[m], mode = m;
+        if (mode == 0)
+            for (int y = 0; y < 16; y++) memcpy(pred16 + 16 * y, rec - (ptrdiff_t)e->cw, 16);
+        else if (mode == 1)
+            for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, rec[(size_t)y * e->cw - 1], 16);
+    }
+    e->mb_i16mode[mb] = (uint8_t)mode;
 
     int dc[16], ydc[16];
     for (int by = 0; by < 4; by++)
         for (int bx = 0; bx < 4; bx++) {
             int16_t res[16], w[16];
             for (int y = 0; y < 4; y++)
-                for (int x = 0; x < 4; x++) res[4 * y + x] = (int16_t)((int)cur[(size_t)(4 * by + y) * e->cw + 4 * bx + x] - dcp);
+                for (int x = 0; x < 4; x++)
+                    res[4 * y + x] = (int16_t)((int)cur[(size_t)(4 * by + y) * e->cw + 4 * bx + x] - (int)pred16[16 * (4 * by + y) + 4 * bx + x]);
             orc_fdct4x4(res, w);
             dc[4 * by + bx] = w[0];
             int blk = -1;
@@ -620,7 +652,7 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
         for (int i = 1; i < 16; i++) d[orc_zigzag4x4[i]] = orc_dequant(lv[blk * 16 + i], qp, orc_zigzag4x4[i]);
         orc_idct4x4(d, r);
         for (int y = 0; y < 4; y++)
-            for (int x = 0; x < 4; x++) rec[(size_t)(4 * by + y) * e->cw + 4 * bx + x] = clip_u8(dcp + r[4 * y + x]);
+            for (int x = 0; x < 4; x++) rec[(size_t)(4 * by + y) * e->cw + 4 * bx + x] = clip_u8((int)pred16[16 * (4 * by + y) + 4 * bx + x] + r[4 * y + x]);
         int n = count_nz(lv + blk * 16, 1, 16);
         e->nnz_l[mb * 16 + 4 * by + bx] = (uint8_t)n;
         ac_flag |= n != 0;
@@ -822,7 +854,7 @@ static void write_mb_intra(orc_enc *e, bw_t *b, int mx, int my, int srow) {
     int mb = my * e->mbw + mx;
     const int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     int cbp = e->mb_cbp[mb], cbpc = cbp >> 4, acf = (cbp & 15) != 0;
-    bw_ue(b, (uint32_t)(1 + 2 /*DC pred*/ + 4 * cbpc + 12 * acf)); /* mb_type, table 7-11 */
+    bw_ue(b, (uint32_t)(1 + e->mb_i16mode[my * e->mbw + mx] + 4 * cbpc + 12 * acf)); /* mb_type, table 7-11: Intra16x16PredMode 0 V, 1 H, 2 DC */
     bw_ue(b, 0);                                                   /* intra_chroma_pred_mode = DC */
     bw_se(b, 0);                                                   /* mb_qp_delta */
     cavlc_block(b, lv + 16 * 16, 16, luma_nc(e, mx, my, 0, 0, srow));

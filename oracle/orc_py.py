@@ -18,7 +18,7 @@ MAX_NALS = 512
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "keyint", "fps_num", "fps_den",
-                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode")]
+                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode", "intra_modes")]
 
 
 class OrcNal(C.Structure):
@@ -91,10 +91,11 @@ class Frame:
 
 
 class Encoder:
-    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False):
-        """rc: picture QP by spec/CODEC.md section 1a (the CRF approximation), qp = its base; else fixed QP."""
+    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False, intra_modes=False):
+        """rc: picture QP by spec/CODEC.md section 1a (the CRF approximation), qp = its base; else fixed QP.
+        intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only."""
         self.L = lib()
-        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)))
+        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(bool(intra_modes)))
         self.h = self.L.orc_enc_open(C.byref(self.params))
         if not self.h:
             raise ValueError("orc_enc_open rejected the parameters")

@@ -432,7 +432,8 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
     t = read_track(data)
     assert t["timescale"] == 24 and t["stts"] == [(n, 1)] and t["stss"] == [1, 4, 7] and (t["width"], t["height"]) == (w, h)
     # the C driver opens the encoder as the reference does: X264_RC_CRF (av_encode.c:400-401) = spec/CODEC.md section 1a
-    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True)
+    # ... and with the preset's intra modes (x264_param_default_preset: Intra16x16 V / H / DC)
+    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True)
     dec = orc.Decoder()
     got = samples_of(data, t)
     for k, f in enumerate(frames):
@@ -582,7 +583,7 @@ def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path)
     assert pct == sorted(pct) and pct[-1] <= 100.0 and pct[-1] > 50.0
     t = read_track(open(mp4, "rb").read())
     assert len(t["stsz"]) == 9 and t["stss"] == [1, 6] and t["timescale"] == 25
-    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True)
+    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True)
     got = samples_of(open(mp4, "rb").read(), t)
     for k in range(9):
         ref = enc.encode(*frames[k])
@@ -643,3 +644,66 @@ def test_rate_control_needs_the_whole_picture(venc):
     with pytest.raises(venc.VencError):
         e.set_band(0, 2)
     e.close()
+
+
+def _stripes_and_texture(venc, w, h, n):
+    """Content on which the three predictors win in turn: vertical stripes (vertical), horizontal stripes (horizontal),
+    smooth texture (DC), changing from region to region."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = []
+    for t in range(n):
+        y, u, v = venc.synth_frame(w, h, t, 11)
+        y = y.copy()
+        y[:, : w // 3] = ((((xx[:, : w // 3] + t) // 3) % 2) * 150 + 40).astype(np.uint8)
+        y[:, w // 3: 2 * w // 3] = ((((yy[:, w // 3: 2 * w // 3] + 2 * t) // 5) % 2) * 120 + 60).astype(np.uint8)
+        out.append((y, u, v))
+    return out
+
+
+@pytest.mark.parametrize("w,h,qp,slices,n", [
+    (352, 288, 26, 4, 3),
+    (178, 146, 30, 3, 3),        # clamped ingest, ragged macroblocks
+    (176, 464, 28, 1, 2),        # 29 macroblock rows in one slice: second chunk reads its top row from memory
+    (1920, 1080, 26, 8, 2),
+    (16, 16, 24, 1, 2),          # one macroblock: only DC is available
+])
+def test_intra16x16_vertical_horizontal_dc_match_oracle(venc, orc, w, h, qp, slices, n):
+    """Intra16x16 prediction modes (spec/CODEC.md section 3): the engine's wavefront kernel
+    k_intra_modes against the oracle, stage by stage -- levels, reconstruction, slice RBSPs (mb_type carries the mode) --
+    on content where each of the three predictors wins somewhere; all-I."""
+    enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=1, threads=8, intra_modes=True)
+    eng = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2, intra_modes=True)
+    modes = set()
+    for t, (y, u, v) in enumerate(_stripes_and_texture(venc, w, h, n)):
+        ref = enc.encode(y, u, v)
+        eng.upload(t % 2, y, u, v)
+        eng.encode_step([t % 2], [t % 2], True, 0, [t & 1])
+        eng.sync()
+        lv_g, lv_o = eng.debug(1), enc.levels()
+        if not np.array_equal(lv_g, lv_o):
+            bad = np.argwhere(lv_g != lv_o)
+            raise AssertionError("levels frame %d: first mismatch mb,blk,idx=%s gpu=%d orc=%d (%d diffs)" % (
+                t, bad[0], lv_g[tuple(bad[0])], lv_o[tuple(bad[0])], len(bad)))
+        rec_o = enc.recon()
+        for p in range(3):
+            assert np.array_equal(eng.debug(4 + p), rec_o[p]), "recon plane %d frame %d" % (p, t)
+        sl_o = [unescape(b) for (ty, _, b) in split_nals(ref.data) if ty in (1, 5)]
+        assert eng.get_slices(t % 2) == sl_o, "slices frame %d" % t
+        modes |= set(int(x) for x in (eng.debug(2)[:, 25] >> 1) & 3)
+    if w >= 176 and h >= 144:
+        assert modes == {0, 1, 2}, modes     # every predictor was chosen somewhere
+    eng.close()
+
+
+def test_x264_api_with_intra_modes_and_rate_control(venc, orc):
+    """What a C caller gets from x264_param_default_preset + X264_RC_CRF (the reference's open sequence,
+    av_encode.c:384-401): Intra16x16 V / H / DC and the CRF approximation together, GOP-batched."""
+    w, h, n, keyint = 352, 288, 16, 4
+    frames = _stripes_and_texture(venc, w, h, n)
+    got = _x264_stream(venc, frames, w, h, slices=4, keyint=keyint, fps=(30, 1), sar=(1, 1), crf=23, gop_batch=2, intra_modes=True)
+    enc = orc.Encoder(w, h, qp=23, n_slices=4, keyint=keyint, fps=(30, 1), sar=(1, 1), threads=8, rc=True, intra_modes=True)
+    dec = orc.Decoder()
+    for t, f in enumerate(frames):
+        ref = enc.encode(*f)
+        assert got[t].payload == ref.data, "frame %d" % t
+        assert dec.decode(got[t].payload) == 1 and np.array_equal(dec.planes()[0], enc.recon()[0])

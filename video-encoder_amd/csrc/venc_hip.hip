@@ -816,8 +816,12 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_intra, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, g, b, S);
         else
 #endif
-        {
-            /* transform off the dependency chain, DC chain, reconstruction (venc_intra2.hip) */
+        if (c->cfg.intra_modes) {
+            /* Intra16x16 vertical / horizontal / DC by SAD: the plain dependency wavefront (venc_intra2.hip k_intra_modes) */
+            const venc_geom &gi = c->cfg.rc_mode ? c->g_idr : g;
+            hipLaunchKernelGGL(k_intra_modes, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, gi, b, S);
+        } else {
+            /* DC prediction only: transform off the dependency chain, DC chain, reconstruction (venc_intra2.hip) */
             const venc_geom &gi = c->cfg.rc_mode ? c->g_idr : g; /* IDR pictures under rate control: their own quantiser constants */
             hipLaunchKernelGGL(k_intra_fwd, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, gi, b, S);
             hipLaunchKernelGGL(k_intra_dc, dim3(band_slices, 1, n_items), dim3(1024), 0, s1, gi, b, S, c->intra_cw);

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_intra_fwd(venc_geom g, venc_bufs B, ven
     if (l32 == 0) {
         info->cbp = (uint8_t)((hnz & 0xffffu) ? 15 : 0);
         info->cbpc = (uint8_t)(((hnz >> 16) & 0xffu) ? 2 : 0); /* 1 (DC only) is decided by k_intra_dc / k_intra_rec */
-        info->flags = 1;
+        info->flags = 1 | (2 << 1); /* Intra16x16, Intra16x16PredMode 2 (DC): the only mode of this path */
         B.mvsad[gmb] = 0;
     }
 }
@@ -390,5 +390,158 @@ __global__ __launch_bounds__(256) void k_intra_rec(venc_geom g, venc_bufs B, ven
 #pragma unroll
         for (int x = 0; x < 4; x++) v |= (uint32_t)intra_px(h[4 * y + x] + d0p) << (8 * x);
         *(uint32_t *)(rec + (size_t)(py + y) * wstride + px) = v;
+    }
+}
+
+/* ================================================================== k_intra_modes
+ * I pictures with Intra16x16 prediction chosen per macroblock among vertical (0), horizontal (1) and DC (2) by the SAD of
+ * the predictor against the source (spec/CODEC.md section 3: smallest SAD, the smaller mode number on ties; vertical
+ * needs the macroblock above, horizontal the one to the left, inside the slice).  Vertical and horizontal predictors are
+ * not constants of the macroblock, so the linearity the three-kernel path above rests on (the predictor shifts
+ * coefficient 0 only) is gone for 7 of a block's 16 coefficients; this kernel is the plain 2-D dependency wavefront
+ * instead: one block per slice, half-wave r owns macroblock row r of the band and runs one macroblock behind half-wave
+ * r - 1, a macroblock's transform on 24 lanes (mb_code), the reconstructed bottom ROW of every macroblock handed down
+ * through a small LDS ring (16 luma + 8 + 8 chroma samples), its right COLUMN handed on in registers.  ~4.5 us per
+ * wavefront step against 0.9 for the DC-only chain -- affordable because intra steps run ahead of their unit on a
+ * stream of their own (venc_hip.hip, INTRA AHEAD): at 1080p the ~0.6 ms of an I step hide behind six P steps. */
+__global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_bot[2 * INTRA_MAX_WAVES][4][8]; /* per macroblock row, ring of 4: bottom row Y[16] Cb[8] Cr[8] */
+    const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
+    const int nw = blockDim.x >> 6;
+    const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
+    const int rw = wv + nw * (lane >> 5); /* each half of a wave owns a macroblock row of the band */
+    const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
+    const bool luma = l32 < 16;
+    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
+    const int k = l32 & 3;
+    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
+
+    int cstride, pw, ph, wstride;
+    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
+    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
+
+    for (int cb = r0; cb < r1; cb += 2 * nw) {
+        const int nr = min(2 * nw, r1 - cb);
+        const int my = cb + rw;
+        const int steps = g.mbw + nr - 1;
+        uint32_t left4 = 0;                      /* luma lanes: the four samples left of this lane's block rows */
+        int leftY = 0, leftC0 = 0, leftC1 = 0;   /* sums of the left column (luma: all 16; chroma: upper / lower half of this lane's plane) */
+        const bool cur_al = luma ? ((g.w & 3) == 0) : ((g.w & 7) == 0);
+        const int pyl = (luma ? my * 16 : my * 8) + by;
+        uint32_t cq[4] = {0, 0, 0, 0};
+        if (rw < nr) load_cur_rows(cur, cstride, pw, ph, bx, pyl, cur_al, cq);
+        for (int step = 0; step < steps; step++) {
+            const int mx = step - rw;
+            if (rw < nr && mx >= 0 && mx < g.mbw) {
+                uint32_t nq[4] = {0, 0, 0, 0};
+                if (mx + 1 < g.mbw) load_cur_rows(cur, cstride, pw, ph, (luma ? (mx + 1) * 16 : (mx + 1) * 8) + bx, pyl, cur_al, nq);
+                const int mb = my * g.mbw + mx;
+                const bool aL = mx > 0, aT = my > r0;
+                /* the row above: 8 dwords Y0..Y3 Cb0 Cb1 Cr0 Cr1 */
+                uint32_t tb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (aT) {
+                    if (rw > 0) {
+                        const uint4 a = *(const uint4 *)&s_bot[rw - 1][mx & 3][0], c4 = *(const uint4 *)&s_bot[rw - 1][mx & 3][4];
+                        tb[0] = a.x, tb[1] = a.y, tb[2] = a.z, tb[3] = a.w, tb[4] = c4.x, tb[5] = c4.y, tb[6] = c4.z, tb[7] = c4.w;
+                    } else {
+                        /* the row above belongs to the previous chunk of this slice: its bottom lines come from memory */
+                        int ys, us;
+                        const uint8_t *ry = rec_plane(B, g, S.parity, item, 0, ys) + (size_t)(my * 16 - 1) * ys + mx * 16;
+                        const uint8_t *ru = rec_plane(B, g, S.parity, item, 1, us) + (size_t)(my * 8 - 1) * us + mx * 8;
+                        const uint8_t *rv = rec_plane(B, g, S.parity, item, 2, us) + (size_t)(my * 8 - 1) * us + mx * 8;
+                        const uint4 a = *(const uint4 *)ry;
+                        const uint2 cu = *(const uint2 *)ru, cv = *(const uint2 *)rv;
+                        tb[0] = a.x, tb[1] = a.y, tb[2] = a.z, tb[3] = a.w, tb[4] = cu.x, tb[5] = cu.y, tb[6] = cv.x, tb[7] = cv.y;
+                    }
+                }
+                const int t0 = (int)__builtin_amdgcn_sad_u8(tb[3], 0u, __builtin_amdgcn_sad_u8(tb[2], 0u, __builtin_amdgcn_sad_u8(tb[1], 0u, __builtin_amdgcn_sad_u8(tb[0], 0u, 0u))));
+                const uint32_t top4 = bx == 0 ? tb[0] : bx == 4 ? tb[1] : bx == 8 ? tb[2] : tb[3]; /* (luma lanes) the four samples above this lane's block columns */
+                int pred; /* the DC predictor of this lane's plane / block */
+                if (luma) {
+                    pred = (aL && aT) ? (leftY + t0 + 16) >> 5 : aL ? (leftY + 8) >> 4 : aT ? (t0 + 8) >> 4 : 128;
+                } else {
+                    const uint32_t tc = tb[4 + 2 * (plane - 1) + (k & 1)];
+                    const int sT = (int)__builtin_amdgcn_sad_u8(tc, 0u, 0u);
+                    const int sL = (k >> 1) ? leftC1 : leftC0;
+                    bool useT = aT, useL = aL;
+                    if (k == 1 && aT) useL = false;
+                    if (k == 2 && aL) useT = false;
+                    pred = (useT && useL) ? (sT + sL + 4) >> 3 : useT ? (sT + 2) >> 2 : useL ? (sL + 2) >> 2 : 128;
+                }
+                /* mode decision over the 16 luma lanes: SAD of the source against each predictor */
+                uint32_t sV = 0, sH = 0, sD = 0;
+                if (luma) {
+                    const uint32_t d4 = (uint32_t)pred * 0x01010101u;
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        sV = __builtin_amdgcn_sad_u8(cq[y], top4, sV);
+                        sH = __builtin_amdgcn_sad_u8(cq[y], ((left4 >> (8 * y)) & 255u) * 0x01010101u, sH);
+                        sD = __builtin_amdgcn_sad_u8(cq[y], d4, sD);
+                    }
+                }
+                sV = half_sum32(sV, lane), sH = half_sum32(sH, lane), sD = half_sum32(sD, lane);
+                int mode = 2;
+                {
+                    uint32_t best = sD;
+                    if (aL && sH <= best) best = sH, mode = 1;
+                    if (aT && sV <= best) best = sV, mode = 0;
+                }
+                const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
+                int c[16], p[16];
+#pragma unroll
+                for (int y = 0; y < 4; y++)
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        c[4 * y + x] = (int)((cq[y] >> (8 * x)) & 255u);
+                        p[4 * y + x] = !luma || mode == 2 ? pred : mode == 0 ? (int)((top4 >> (8 * x)) & 255u) : (int)((left4 >> (8 * y)) & 255u);
+                    }
+#pragma unroll
+                for (int y = 0; y < 4; y++) cq[y] = nq[y];
+                mb_lane_out o;
+                mb_code<true, true>(lane, c, p, g, o);
+
+                int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
+                venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+                mb_store(l32, true, o, lv_mb, info, rec, wstride, px, py);
+                if (luma) { /* luma DC record (slot 16, zig-zag order) */
+                    const int rp = blk_y(l32) * 4 + blk_x(l32);
+                    int zi = 0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++)
+                        if (venc_zigzag_ct(i) == rp) zi = i;
+                    lv_mb[16 * 16 + zi] = (int16_t)o.dclv;
+                }
+                const int dc0 = __shfl(o.dclv, hbase | (l32 & 28) | 0), dc1 = __shfl(o.dclv, hbase | (l32 & 28) | 1);
+                const int dc2 = __shfl(o.dclv, hbase | (l32 & 28) | 2), dc3 = __shfl(o.dclv, hbase | (l32 & 28) | 3);
+                if (l32 == 16 || l32 == 20) {
+                    uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
+                    dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16), ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
+                }
+                const uint32_t hnz = (uint32_t)(__ballot(o.nnz > 0) >> hbase), hdc = (uint32_t)(__ballot(o.dclv != 0) >> hbase);
+                if (l32 == 0) {
+                    info->cbp = (uint8_t)((hnz & 0xffffu) ? 15 : 0);
+                    info->cbpc = (uint8_t)(((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0);
+                    info->flags = (uint8_t)(1 | (mode << 1)); /* bit 0: Intra16x16; bits 1-2: Intra16x16PredMode */
+                    B.mvsad[(size_t)item * g.nmb + mb] = 0;
+                }
+                /* reconstructed edges for the neighbours: bottom row to the ring, right column to the next step */
+                const uint32_t pbq = (uint32_t)o.rec[12] | ((uint32_t)o.rec[13] << 8) | ((uint32_t)o.rec[14] << 16) | ((uint32_t)o.rec[15] << 24);
+                const uint32_t prq = (uint32_t)o.rec[3] | ((uint32_t)o.rec[7] << 8) | ((uint32_t)o.rec[11] << 16) | ((uint32_t)o.rec[15] << 24);
+                if (luma ? by == 12 : (l32 < 24 && by == 4)) s_bot[rw][mx & 3][luma ? (bx >> 2) : 4 + 2 * (plane - 1) + (k & 1)] = pbq;
+                const int pr = o.rec[3] + o.rec[7] + o.rec[11] + o.rec[15];
+                const uint32_t c0 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 0)), c1 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 1));
+                const uint32_t c2 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 2)), c3 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 3));
+                left4 = by == 0 ? c0 : by == 4 ? c1 : by == 8 ? c2 : c3;
+                leftY = (int)__builtin_amdgcn_sad_u8(c3, 0u, __builtin_amdgcn_sad_u8(c2, 0u, __builtin_amdgcn_sad_u8(c1, 0u, __builtin_amdgcn_sad_u8(c0, 0u, 0u))));
+                const int rcb0 = __shfl(pr, hbase | 17), rcb1 = __shfl(pr, hbase | 19), rcr0 = __shfl(pr, hbase | 21), rcr1 = __shfl(pr, hbase | 23);
+                leftC0 = plane == 2 ? rcr0 : rcb0;
+                leftC1 = plane == 2 ? rcr1 : rcb1;
+            }
+            /* LDS-only barrier (no wait for the global stores and prefetches of the step) */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+        __syncthreads(); /* the next chunk re-reads this chunk's last reconstructed row from memory */
     }
 }

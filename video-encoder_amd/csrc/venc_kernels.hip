@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256) void k_me_dense(venc_geom g, venc_bufs B, venc
     }
 }
 
+#endif /* VENC_LEGACY_KERNELS */
+
 /* ================================================================== macroblock transform core
  * Lane roles inside a 32-lane macroblock team: l32 0..15 = luma4x4BlkIdx,
  * 16..19 = Cb block k, 20..23 = Cr block k, 24..31 spare.  Every lane of the
@@ -372,6 +374,7 @@ DEVFN void mb_store(int l32, bool valid, const mb_lane_out &o, int16_t *lv_mb, v
     }
 }
 
+#ifdef VENC_LEGACY_KERNELS
 /* ================================================================== k_inter
  * P_L0_16x16: half-wave per macroblock, 8 macroblocks per block. */
 __global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_step S) {
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_s
                     int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
                     info->cbp = (uint8_t)cbpl;
                     info->cbpc = (uint8_t)cbpc;
-                    info->flags = 1;
+                    info->flags = 1 | (2 << 1);
                     B.mvsad[(size_t)item * g.nmb + mb] = 0;
                 }
                 /* neighbour sums for the next macroblocks */
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     if (l32 == 0 && valid) {
         if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item, B);
         if (i16) {
-            venc_bs_ue(&bs, (uint32_t)(1 + 2 + 4 * cbpc + 12 * (cbpl != 0)));
+            venc_bs_ue(&bs, (uint32_t)(1 + (int)((o1.z >> 9) & 3u) + 4 * cbpc + 12 * (cbpl != 0))); /* mb_type (table 7-11) carries Intra16x16PredMode: flags bits 1-2 */
             venc_bs_ue(&bs, 0);
             venc_bs_se(&bs, 0);
         } else {
