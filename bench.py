@@ -186,7 +186,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             xc = dmod.BandExchange(dmod.EnginePort(local_rank), wl["slices"], world, rank, halo_rows=args.halo)
             band_kw = dict(slice_first=s0, slice_count=cnt, exchange=xc)
     enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
-                           gop_batch=gop_batch, device=local_rank, **band_kw)
+                           gop_batch=gop_batch, device=local_rank, intra_modes=args.intra_modes, crf=args.crf, **band_kw)
     if not args.no_profile:
         enc.profile(True, capacity=8 * frames * max(2, steps, warmup))
         # timed region: HIP-event pairs around the dominant kernel only (each pair stalls the stream for a
@@ -289,6 +289,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                            world, "halo (%d luma rows per edge)" % args.halo if args.halo else "whole-band", args.backend))
                        if slices_mode else ("1 stream per GPU, no collective" if world > 1 else "single GPU"),
                        "steps_pipelined": pipelined,
+                       "intra_modes": "V/H/DC" if args.intra_modes else "DC", "rate_control": ("crf %g" % args.crf) if args.crf is not None else "fixed QP",
                        "bytes_per_step": bytes_per_step,
                        "bitstream_fnv1a": "%016x" % tally.fnv1a if tally else None,
                        "cpu_oracle_note": ORACLE_NOTE},
@@ -382,6 +383,8 @@ def main():
     ap.add_argument("--mode", default="streams", choices=("streams", "slices"),
                     help="streams: one clip per GPU, no collective (default); slices: one clip, slice bands across GPUs")
     ap.add_argument("--halo", type=int, default=16, help="slices mode: luma rows exchanged per band edge (0 = whole bands)")
+    ap.add_argument("--intra-modes", action="store_true", help="Intra16x16 vertical / horizontal / DC by SAD in I pictures (default: DC only, the definition the metric's digests are frozen on); not a headline configuration")
+    ap.add_argument("--crf", type=float, default=None, help="X264_RC_CRF with this rate factor instead of fixed QP (spec/CODEC.md section 1a); not a headline configuration")
     ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 

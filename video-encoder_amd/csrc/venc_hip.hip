@@ -62,6 +62,7 @@ static thread_local char g_err[512] = "";
  * ring of VENC_RECON reconstruction buffers the I step is launched on a THIRD stream as soon as the buffer it will write is
  * idle -- the P step VENC_RECON - 1 before it has finished with it -- and runs beside the last P steps of the previous unit instead
  * of between the units.  The main stream picks the chain up again with the first P step (one event). */
+#define VENC_QP_RING 16
 #define VENC_RECON 8 /* (the buffer step N writes was read last by step N - 7: at least four steps of overlap with batches of four) */
 #define VENC_BHIST 8
 
@@ -87,7 +88,10 @@ struct venc_ctx {
     /* rate control (cfg.rc_mode; spec/CODEC.md section 1a) */
     venc_geom g_idr;                  /* geometry with the quantiser constants of IDR pictures (base - 3) */
     unsigned long long *d_sad_sum;    /* [3][G] per-item sums of best SADs, rotating between P steps */
-    int *d_qp_ring;                   /* [VENC_RING][G] QP each (step, item) was coded at */
+    int *d_qp_ring;                   /* [VENC_QP_RING][G] QP each (step, item) was coded at; slot = step % 16: written one step ahead, read by the
+                                         entropy batch up to a few steps later -- twice the step ring, so that the early write never meets a late read */
+    venc_qparams *d_qtab;             /* [52] */
+    uint32_t *d_fix_done;             /* [G] */
     int rc_phase;                     /* set the next P step adds to */
     int last_step_p;                  /* the previous step was a P step */
     hipEvent_t ev_side[VENC_RING];    /* per ring slot: the entropy kernels that read the slot's motion vectors, levels and records are done */
@@ -277,6 +281,8 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.fix_count);
     (void)hipFree(c->d_sad_sum);
     (void)hipFree(c->d_qp_ring);
+    (void)hipFree(c->d_qtab);
+    (void)hipFree(c->d_fix_done);
     (void)hipFree(c->b.intra_rec);
     (void)hipFree(c->b.intra_d0);
     (void)hipFree(c->b.fix_list);
@@ -554,8 +560,17 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         fill_qparams(&c->g_idr.qc, qi < 30 ? qi : h_qpc_hi[qi - 30]);
         OPEN_OK(hipMalloc(&c->d_sad_sum, 3 * G * sizeof(unsigned long long)));
         OPEN_OK(hipMemset(c->d_sad_sum, 0, 3 * G * sizeof(unsigned long long)));
-        OPEN_OK(hipMalloc(&c->d_qp_ring, VENC_RING * G * sizeof(int)));
-        OPEN_OK(hipMemset(c->d_qp_ring, 0, VENC_RING * G * sizeof(int)));
+        OPEN_OK(hipMalloc(&c->d_qp_ring, VENC_QP_RING * G * sizeof(int)));
+        OPEN_OK(hipMemset(c->d_qp_ring, 0, VENC_QP_RING * G * sizeof(int)));
+        OPEN_OK(hipMalloc(&c->d_fix_done, G * sizeof(uint32_t)));
+        OPEN_OK(hipMemset(c->d_fix_done, 0, G * sizeof(uint32_t)));
+        venc_qparams qt[52];
+        memset(qt, 0, sizeof(qt));
+        for (int q = 0; q < 52; q++) fill_qparams(&qt[q], q);
+        OPEN_OK(hipMalloc(&c->d_qtab, sizeof(qt)));
+        OPEN_OK(hipMemcpy(c->d_qtab, qt, sizeof(qt), hipMemcpyHostToDevice));
+        b.qtab = c->d_qtab;
+        b.fix_done = c->d_fix_done;
     }
     OPEN_OK(hipMalloc(&b.fix_count, 2 * G * 4));
     OPEN_OK(hipMalloc(&b.intra_rec, G * nmb * INTRA_REC_DWORDS * 4));
@@ -759,7 +774,8 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
     if (c->cfg.rc_mode) {
         const size_t G_ = (size_t)c->b.max_items;
-        b.qp_cur = c->d_qp_ring + (size_t)rs * G_;
+        b.qp_cur = c->d_qp_ring + (size_t)(c->step_no % VENC_QP_RING) * G_;
+        b.qp_next = c->d_qp_ring + (size_t)((c->step_no + 1) % VENC_QP_RING) * G_;
         if (!is_idr) {
             b.sad_prev = c->d_sad_sum + (size_t)((c->rc_phase + 2) % 3) * G_;
             b.sad_cur = c->d_sad_sum + (size_t)c->rc_phase * G_;
@@ -950,7 +966,7 @@ static int entropy_flush(venc_ctx *c) {
     b.mvsad = c->b.mvsad + (size_t)rs0 * GN;
     b.levels = c->b.levels + (size_t)rs0 * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs0 * GN;
-    if (c->cfg.rc_mode) b.qp_cur = c->d_qp_ring + (size_t)rs0 * c->b.max_items;
+    if (c->cfg.rc_mode) b.qp_cur = c->d_qp_ring + (size_t)(c->eb_first_step % VENC_QP_RING) * c->b.max_items;
     b.unit_count = c->b.unit_count + (size_t)c->unit_phase * c->b.vcap * VENC_COUNTER_STRIDE;
     b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.vcap * VENC_COUNTER_STRIDE;
     if (!is_idr) c->unit_phase ^= 1;
@@ -975,7 +991,7 @@ static int entropy_flush(venc_ctx *c) {
             bk.mvsad = c->b.mvsad + (size_t)rsk * GN;
             bk.levels = c->b.levels + (size_t)rsk * GN * VENC_MB_COEFS;
             bk.mbinfo = c->b.mbinfo + (size_t)rsk * GN;
-            if (c->cfg.rc_mode) bk.qp_cur = c->d_qp_ring + (size_t)rsk * c->b.max_items;
+            if (c->cfg.rc_mode) bk.qp_cur = c->d_qp_ring + (size_t)((c->eb_first_step + k) % VENC_QP_RING) * c->b.max_items;
             prof_begin(c, KID_INTER, s2);
             hipLaunchKernelGGL(k_inter_fused, dim3((band_mbs + 31) / 32, 1, c->eb_step[k].n_items), dim3(256), 0, s2, g, bk, c->eb_step[k], 0);
             prof_end(c, s2);

@@ -131,8 +131,8 @@ DEVFN void unpack4(uint32_t v, int *o) {
 DEVFN void step_qparams(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, venc_qparams &ql, venc_qparams &qc) {
     if (S.rc_mode) {
         const int qp = B.qp_cur[item];
-        venc_make_qparams(qp, &ql);
-        venc_make_qparams(venc_chroma_qp(qp), &qc);
+        ql = B.qtab[qp];
+        qc = B.qtab[venc_chroma_qp(qp)];
     } else {
         ql = g.ql;
         qc = g.qc;

@@ -133,7 +133,10 @@ typedef struct {
      * and the QP each (step, item) was coded at, in the step ring, for the kernels that run later (chroma, entropy) */
     const unsigned long long *sad_prev;
     unsigned long long *sad_cur, *sad_next;
-    int *qp_cur;
+    int *qp_cur;                /* [G] this step's slot of the QP ring (16 steps) */
+    int *qp_next;               /* [G] the next step's slot: written by the last block of this step's k_me_fix from the final SAD sum */
+    uint32_t *fix_done;         /* [G] k_me_fix blocks that have finished (zero between launches) */
+    const venc_qparams *qtab;   /* [52] quantiser constants of every QP (built by the host at open) */
     uint8_t *out_hdr;           /* device view of the pinned header pool: per slot venc_out_header + slice table */
     size_t out_hdr_stride;
     uint8_t *out_data;          /* per slot data[]: HBM staging buffer, or the device view of the pinned host pool */

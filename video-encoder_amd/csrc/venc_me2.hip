@@ -315,7 +315,9 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     const int item = blockIdx.z, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
-    if (blockIdx.x >= count) return;
+    /* blocks with a listed macroblock (under rate control: block 0 too when nothing is listed: somebody has to close the sum) */
+    const uint32_t reporting = S.rc_mode ? max(1u, min(count, (uint32_t)gridDim.x)) : count;
+    if (blockIdx.x >= reporting) return;
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     /* the ranks of this lane's candidates do not depend on the macroblock: fetched before anything else, used last */
     uint32_t rk[FIX_NDY];
 #pragma unroll
-    for (int k = 0; k < FIX_NDY; k++) rk[k] = (dy0 + k <= 32 && lane < 33) ? (uint32_t)B.me_rank[(dy0 + k) * 33 + dxi] : 0x7ffu;
+    for (int k = 0; k < FIX_NDY; k++) rk[k] = (blockIdx.x < count && dy0 + k <= 32 && lane < 33) ? (uint32_t)B.me_rank[(dy0 + k) * 33 + dxi] : 0x7ffu;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
         const int mb = (int)B.fix_list[(size_t)item * g.nmb + i];
         const int mx = mb % g.mbw, my = mb / g.mbw;
@@ -427,6 +429,20 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
             }
             if (fuse_luma > 1 && tid >= 64 && tid < 128) /* its chroma transform: lanes 0-7 of wave 1 */
                 inter_chroma_mb(g, B, S, item, lane, mb, lane < 8, s_mv[0] - 16, s_mv[1] - 16, qcf);
+        }
+    }
+    /* Rate control: the picture's SAD sum is final once every block of this launch has made its corrections.  The block that
+     * reports in last derives the NEXT picture's QP from it (spec/CODEC.md section 1a: the one 64-bit division per picture
+     * and item) and leaves it in the next step's slot of the QP ring, where that step's kernels find it. */
+    if (S.rc_mode) {
+        __syncthreads(); /* (waits for this block's outstanding memory operations, its atomic corrections among them: they are
+                            acknowledged by L2, where the sum lives, before the arrival below is issued) */
+        if (tid == 0) {
+            if (atomicAdd(&B.fix_done[item], 1u) == reporting - 1u) {
+                B.fix_done[item] = 0u; /* for the next launch (same stream: ordered) */
+                const unsigned long long sum = atomicAdd(&B.sad_cur[item], 0ull);
+                B.qp_next[item] = venc_rc_qp(S.qp_base, 0, 1, sum, g.nmb);
+            }
         }
     }
 }

@@ -124,8 +124,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     if (tile >= tiles_x * tiles_y) return;
     if (tile == 0 && threadIdx.x == 0) {
         B.fix_count_next[item] = 0; /* the other counter: the next P step's search fills it, nobody reads it now */
-        if (RC) {                   /* rate control: this picture's QP for the kernels that run later; the next step's SAD sum starts at zero */
-            B.qp_cur[item] = venc_rc_qp(S.qp_base, 0, S.rc_history, B.sad_prev[item], g.nmb);
+        if (RC) { /* rate control: the next step's SAD sum starts at zero; a first P picture of a GOP is coded at the base QP (every
+                     other picture's QP was left in the ring by the last block of the previous step's k_me_fix) */
+            if (!S.rc_history) B.qp_cur[item] = S.qp_base;
             B.sad_next[item] = 0ull;
         }
     }
@@ -451,13 +452,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * dequantisation, inverse transform, reconstruction, levels (venc_inter2.hip luma_block_code).  16 macroblocks x 16
      * blocks = the lanes of waves 0-3; macroblocks listed for k_me_fix are left to it.  The transform no longer re-reads
      * the two luma planes from memory and costs the main chain no launch of its own. ---- */
-    /* the pictures' quantiser constants: fixed, or from the QP every block derives alike from the previous picture's SAD
-     * sum (spec/CODEC.md section 1a) */
+    /* the pictures' quantiser constants: fixed, or those of the QP chosen from the previous picture's SAD sum
+     * (spec/CODEC.md section 1a; one table load -- the division of the rule is done once per picture, in k_me_fix) */
     venc_qparams ql5 = g.ql, qc5 = g.qc;
     if (RC) {
-        const int qp5 = venc_rc_qp(S.qp_base, 0, S.rc_history, B.sad_prev[item], g.nmb);
-        venc_make_qparams(qp5, &ql5);
-        venc_make_qparams(venc_chroma_qp(qp5), &qc5);
+        const int qp5 = S.rc_history ? B.qp_cur[item] : S.qp_base;
+        ql5 = B.qtab[qp5];
+        qc5 = B.qtab[venc_chroma_qp(qp5)];
         if (threadIdx.x >= 448) { /* wave 7 has nothing to do in P5: this tile's share of the picture's SAD sum, one atomic per block */
             const int l7 = threadIdx.x - 448;
             uint32_t sad = 0;
