@@ -887,7 +887,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */
         if (flags_mbs) {
             prof_begin(c, KID_MEFIX, s1);
-            hipLaunchKernelGGL(k_me_fix, dim3(FIX_BLOCKS, 1, n_items), dim3(64 * FIX_WAVES), 0, s1, g, b, S, fuse_arg);
+            if (c->cfg.rc_mode)
+                hipLaunchKernelGGL(k_me_fix<true>, dim3(FIX_BLOCKS, 1, n_items), dim3(64 * FIX_WAVES), 0, s1, g, b, S, fuse_arg);
+            else
+                hipLaunchKernelGGL(k_me_fix<false>, dim3(FIX_BLOCKS, 1, n_items), dim3(64 * FIX_WAVES), 0, s1, g, b, S, fuse_arg);
             prof_end(c, s1);
         }
 #ifdef VENC_LEGACY_KERNELS

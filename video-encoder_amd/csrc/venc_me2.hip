@@ -307,6 +307,7 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
                        current block and the block-wide barriers whatever its share of the search.) */
 #define FIX_WAVES 4
 
+template <bool RC> /* rate-control variant, as k_me_pool's */
 __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_bufs B, venc_step S, int fuse_luma) {
     __shared__ uint32_t s_win[(48 + 4) * FIX_WD];
     __shared__ uint32_t s_cur[16 * 4];
@@ -316,13 +317,13 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     const int wave = tid >> 6, lane = tid & 63;
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
     /* blocks with a listed macroblock (under rate control: block 0 too when nothing is listed: somebody has to close the sum) */
-    const uint32_t reporting = S.rc_mode ? max(1u, min(count, (uint32_t)gridDim.x)) : count;
+    const uint32_t reporting = RC ? max(1u, min(count, (uint32_t)gridDim.x)) : count;
     if (blockIdx.x >= reporting) return;
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
-    venc_qparams qlf, qcf;
-    step_qparams(g, B, S, item, qlf, qcf);
+    venc_qparams qlf = g.ql, qcf = g.qc;
+    if (RC) step_qparams(g, B, S, item, qlf, qcf);
     const int dy0 = wave * FIX_NDY;          /* first dy index of this wave */
     const int dxi = lane < 33 ? lane : 32;   /* lanes 33..63 repeat column 32 and are ignored */
     /* the ranks of this lane's candidates do not depend on the macroblock: fetched before anything else, used last */
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
         for (int k = 1; k < FIX_WAVES; k++) best = min(best, s_best[k]);
         if (mine == best) {
             const int dx = dxi - 16, dy = dy0 + mine_k - 16;
-            if (S.rc_mode) { /* the picture's SAD sum holds what k_me_pool found for this macroblock: correct it */
+            if (RC) { /* the picture's SAD sum holds what k_me_pool found for this macroblock: correct it */
                 const uint32_t old = B.mvsad[(size_t)item * g.nmb + mb] >> 16;
                 atomicAdd(&B.sad_cur[item], (unsigned long long)(long long)((int)(best >> 11) - (int)old));
             }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     /* Rate control: the picture's SAD sum is final once every block of this launch has made its corrections.  The block that
      * reports in last derives the NEXT picture's QP from it (spec/CODEC.md section 1a: the one 64-bit division per picture
      * and item) and leaves it in the next step's slot of the QP ring, where that step's kernels find it. */
-    if (S.rc_mode) {
+    if (RC) {
         __syncthreads(); /* (waits for this block's outstanding memory operations, its atomic corrections among them: they are
                             acknowledged by L2, where the sum lives, before the arrival below is issued) */
         if (tid == 0) {
