@@ -15,5 +15,5 @@ for t in range(8):
     if t:
         c = eng.debug(9).astype(np.int64); f = eng.debug(10)
         q = np.percentile(c, [50, 90, 99, 99.9])
-        print("frame %d: mean %.2f  p50 %d p90 %d p99 %d p99.9 %d  >64: %d  >=255: %d  flagged %d of %d  total survivors %d" % (
-            t, c.mean(), q[0], q[1], q[2], q[3], (c > 64).sum(), (c >= 255).sum(), int(f.sum()), c.size, c.sum()))
+        print("frame %d: mean %.2f  p50 %d p90 %d p99 %d p99.9 %d  >16: %d >32: %d >64: %d  >=255: %d  flagged %d of %d  total survivors %d" % (
+            t, c.mean(), q[0], q[1], q[2], q[3], (c > 16).sum(), (c > 32).sum(), (c > 64).sum(), (c >= 255).sum(), int(f.sum()), c.size, c.sum()))

@@ -150,7 +150,7 @@ struct venc_ctx {
     int steps_done;
     int band_s0, band_s1; /* slices coded by this context (venc_set_band); whole picture by default */
     int slice_rows[VENC_MAX_SLICES + 1];
-    int me_stop;
+    int me_stop, me_fast;
     int inter_legacy; /* VENC_INTER=legacy: the first, half-wave-per-macroblock k_inter */
     int me_mode;  /* 0 pool (default): k_me_pool, successive elimination with in-kernel sums, pooled survivors, three
                      blocks per CU; 3 tile: its predecessor k_me_tile; 1 plane: sums from k_refsum; 2 dense: exhaustive
@@ -542,6 +542,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         if (getenv("VENC_ME_DENSE") && atoi(getenv("VENC_ME_DENSE")) != 0) c->me_mode = 2;
     }
     c->me_stop = getenv("VENC_ME_STOP") ? atoi(getenv("VENC_ME_STOP")) : 0;
+    c->me_fast = getenv("VENC_ME_FAST") ? atoi(getenv("VENC_ME_FAST")) : 1;
     c->me_xcd = getenv("VENC_ME_XCD") && atoi(getenv("VENC_ME_XCD")) != 0;
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
@@ -740,6 +741,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.qp_idr = c->g_idr.qp;
     S.rc_history = !is_idr && c->last_step_p;
     S.me_stop = c->me_stop;
+    S.me_fast = c->me_fast;
     S.slice0 = c->band_s0;
     S.slice1 = c->band_s1;
     S.row0 = c->slice_rows[c->band_s0];

@@ -128,11 +128,21 @@ DEVFN void unpack4(uint32_t v, int *o) {
  * wave's group of 16; every lane of the wave calls this (ballots), `valid` guards the stores */
 /* quantiser constants of this step's pictures: the encoder's fixed ones, or under rate control those of the QP the search
  * chose for (step, item) (B.qp_cur, written by the first tile of k_me_pool before any kernel that calls this runs) */
+/* one row of the QP table into scalar registers: the row index is uniform, but loaded through a plain pointer the 13
+ * constants land in vector registers (26 per pair of tables -- the fused kernels then spill around their transform) */
+DEVFN venc_qparams qparams_uniform(const venc_qparams *row) {
+    venc_qparams q;
+    const int *src = (const int *)row;
+    int *dst = (int *)&q;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(venc_qparams) / sizeof(int)); i++) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    return q;
+}
 DEVFN void step_qparams(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, venc_qparams &ql, venc_qparams &qc) {
     if (S.rc_mode) {
-        const int qp = B.qp_cur[item];
-        ql = B.qtab[qp];
-        qc = B.qtab[venc_chroma_qp(qp)];
+        const int qp = __builtin_amdgcn_readfirstlane(B.qp_cur[item]); /* uniform: the tables load into scalar registers */
+        ql = qparams_uniform(B.qtab + qp);
+        qc = qparams_uniform(B.qtab + venc_chroma_qp(qp));
     } else {
         ql = g.ql;
         qc = g.qc;

@@ -74,6 +74,7 @@ typedef struct {
     /* band of the picture coded by this context (slice-parallel multi-GPU mode, venc_set_band);
      * the whole picture by default: slices [slice0, slice1) = MB rows [row0, row1) = macroblocks [mb0, mb1) */
     int slice0, slice1, row0, row1, mb0, mb1;
+    int me_fast; /* k_me_pool: bounds tested as they are computed (VENC_ME_FAST=0: always the kept-bounds pass) */
     int me_stop; /* diagnostic (VENC_ME_STOP=n): k_me_tile returns after phase n; results are then meaningless */
     int in_slot[VENC_MAX_ITEMS];
     int out_slot[VENC_MAX_ITEMS];

@@ -27,6 +27,12 @@
  *     from (all reads, a barrier, all writes): 51 KB of LDS per block instead of 68, and the register
  *     budget is held at 84, so six waves per SIMD hide the LDS and DPP latencies that four left bare.
  *
+ *  6. THE BOUNDS ARE TESTED AS THEY ARE COMPUTED (round 2).  Start points first (last frame's vector, zero vector);
+ *     their smaller SAD prunes the 1089 bounds on the fly, four rows per wave-uniform branch, nothing kept.  Only a
+ *     wave whose start points were poor (> T3_RETRY survivors in one of its macroblocks) computes the bounds again,
+ *     keeps them, takes the candidate with the smallest bound as a third start point and rebuilds its segment --
+ *     which every wave did before.  843 -> 771 VALU instructions per wave; 2160p launch 284 -> 270 us.
+ *
  * Tried and dropped (measured, same clip): (a) searching the macroblocks with too many survivors exhaustively
  * at the end of their own block, from the window already in LDS, instead of listing them for k_me_fix: such
  * macroblocks cluster, a tile with 16 of them became a 40 us straggler and the launch grew from 83 to 109 us;
@@ -38,6 +44,9 @@
 
 #define T3_POOL 1024 /* survivor pool of a tile = 8 wave segments of 2 x T3_CAP; entry = (LB << 15) | (macroblock << 11) | candidate */
 #define T3_CAP SEA_LIST /* survivors one macroblock may put into the pool (64); more: exhaustive search by k_me_fix */
+#ifndef T3_RETRY
+#define T3_RETRY 32 /* a wave one of whose macroblocks keeps more survivors than this takes the second pass (third start point) */
+#endif
 #define T3_CW 36 /* current tile row stride in dwords: 128 pixels + 16 bytes.  A SAD's 16 lanes read 16 bytes each of 16 consecutive rows
                     (ds_read_b128, banks of 64 dwords): at a stride of 32 dwords rows r and r + 2 share their banks -- an 8-way conflict,
                     28 extra LDS cycles per read, the 5.7 M conflict cycles per launch of the round-1 counters; at 36 the 16 rows
@@ -256,94 +265,48 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     const uint2 c8 = *(const uint2 *)s_c8[hw];
     const uint32_t cleft = c8.x, cright = c8.y; /* (top, bottom) sums of the left / right 8x8 columns */
 
-    /* ---- P3: packed lower bounds pk = LB << 6 | cy; lane = window column cx = l32, one register per vertical
-     * displacement: LB = |V_left - (TL,BL)| + |V_right - (TR,BR)|, two v_sad_u16 on packed u16 pairs ---- */
     const uint32_t *v8 = (const uint32_t *)s_v8;
-    uint32_t pk[33];
-    {
-        const uint32_t *colp = v8 + row0 * T2_SU + col0 + l32;
-        /* batches of 6 rows: at most 12 sums in flight (one batch of 33 would hold 66 registers and the sixth wave) */
-#pragma unroll
-        for (int c0 = 0; c0 < 33; c0 += 6) {
-#pragma unroll
-            for (int cy = c0; cy < (c0 + 6 < 33 ? c0 + 6 : 33); cy++) {
-                const uint32_t lb =
-                    __builtin_amdgcn_sad_u16(colp[cy * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[cy * T2_SU], cleft, 0u));
-                pk[cy] = (lb << 6) | (uint32_t)cy;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    uint32_t lbx0, lbx1 = 0xffffffffu; /* column cx = 32: lane l32 owns cy = l32, lane 0 also cy = 32 */
-    {
-        const uint32_t *colp = v8 + row0 * T2_SU + col0 + 32;
-        lbx0 = __builtin_amdgcn_sad_u16(colp[l32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[l32 * T2_SU], cleft, 0u));
-        if (l32 == 0) lbx1 = __builtin_amdgcn_sad_u16(colp[32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[32 * T2_SU], cleft, 0u));
-    }
-    /* candidate with the smallest bound (any of them on ties: start points only steer the pruning) */
-    int ai, acx, acy; /* candidate with the smallest bound: index and window position */
-    {
-        uint32_t m = pk[0];
-#pragma unroll
-        for (int cy = 1; cy < 33; cy += 2) m = min(min(m, pk[cy]), pk[cy + 1]);
-        uint32_t lmin = ((m >> 6) << 12) | ((m & 63u) << 6) | (uint32_t)l32; /* LB << 12 | cy << 6 | cx */
-        lmin = min(lmin, (lbx0 << 12) | ((uint32_t)l32 << 6) | 32u);
-        if (l32 == 0) lmin = min(lmin, (lbx1 << 12) | (32u << 6) | 32u);
-        const uint32_t w = half_min32(lmin, lane);
-        acy = (int)((w >> 6) & 63u), acx = (int)(w & 63u);
-        ai = acy * 33 + acx;
-    }
-    /* The lane's indices are derived again from an opaque copy of the thread id: the first copies die with P3, where
-     * the 33 bounds plus the sums in flight set the kernel's register peak (88 against the 80 that six waves per SIMD
-     * allow; capped by the compiler alone, the excess became 80 MB of scratch traffic per launch). */
-    {
-    int tid_b = threadIdx.x;
-    asm volatile("" : "+v"(tid_b));
-    const int tid = tid_b;
-    const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32, hw = tid >> 5;
-    const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
-    const int col0 = mbx * 16, row0 = mby * 16;
-    const int mx = tx * T2_MBX + mbx, my = S.row0 + ty * T2_MBY + mby;
-    const bool mb_valid = mx < g.mbw && my < S.row1;
-    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
     const uint32_t prev = s_prev[hw];
-    if (S.me_stop == 4) {
-        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = (uint32_t)ai << 16;
-        return;
-    }
-    /* ---- P4a: two start points per macroblock in one quarter-wave pass: last frame's vector (the zero vector on
-     * still content and after an IDR picture) | the candidate with the smallest bound ---- */
+    /* ---- P3: two start points per macroblock in one quarter-wave pass: last frame's vector | the zero vector.  Their
+     * smaller SAD is the threshold of the bound test (any real SAD is a valid threshold: start points only steer the
+     * pruning, the result is the exact minimum either way). ---- */
     const int pcx = (int)(int8_t)(prev & 255u) + 16, pcy = (int)(int8_t)((prev >> 8) & 255u) + 16;
-    const int ci_p = pcy * 33 + pcx;
+    const int ci_p = pcy * 33 + pcx, ci_z = 16 * 33 + 16;
     uint32_t thr;
     {
         const bool second = (lane & 16) != 0;
-        const uint32_t rank_p = rank[ci_p], rank_a = rank[ai]; /* issued before the SAD, used after it */
-        const uint32_t a = me3_quarter_sad(s_win, s_cur, col0, row0, lane, second ? acx : pcx, second ? acy : pcy);
+        const uint32_t rank_p = rank[ci_p], rank_z = rank[ci_z]; /* issued before the SAD, used after it */
+        const uint32_t a = me3_quarter_sad(s_win, s_cur, col0, row0, lane, second ? 16 : pcx, second ? 16 : pcy);
         /* quarter totals sit in lanes 15 / 31 / 47 / 63: quarters 0, 1 belong to the wave's first macroblock (last
-         * frame's vector, smallest bound), quarters 2, 3 to its second -- no cross-lane exchange beyond the readlanes */
+         * frame's vector, zero vector), quarters 2, 3 to its second -- no cross-lane exchange beyond the readlanes */
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), q1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 31);
         const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47), q3 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
-        const uint32_t sad_p = lane < 32 ? q0 : q2, sad_a = lane < 32 ? q1 : q3;
-        thr = min(sad_p, sad_a);
+        const uint32_t sad_p = lane < 32 ? q0 : q2, sad_z = lane < 32 ? q1 : q3;
+        thr = min(sad_p, sad_z);
         if (l32 == 0) {
             const unsigned long long kp = ((unsigned long long)((sad_p << 11) | rank_p) << 11) | (uint32_t)ci_p;
-            const unsigned long long ka = ((unsigned long long)((sad_a << 11) | rank_a) << 11) | (uint32_t)ai;
-            s_best[hw] = kp < ka ? kp : ka;
+            const unsigned long long kz = ((unsigned long long)((sad_z << 11) | rank_z) << 11) | (uint32_t)ci_z;
+            s_best[hw] = kp < kz ? kp : kz;
             s_ovf[hw] = 0;
         }
     }
-    if (S.me_stop == 6) { /* diagnostic: start points done, scan not started */
+    if (S.me_stop == 4) { /* diagnostic: start points done, bounds not started */
         if (l32 == 0 && mb_valid) B.mvsad[mbidx] = thr << 16;
         return;
     }
-    /* ---- survivors: bound <= best start SAD, appended to the tile's pool.  Every wave owns a segment of the pool
-     * (2 macroblocks x T3_CAP entries) and compacts into it with wave ballots: no atomics, no pool-full case.  Rows are
-     * tested four at a time; most groups hold no survivor.  A macroblock with more than T3_CAP survivors is listed for
-     * the exhaustive search (k_me_fix). ---- */
+    /* ---- P4a: lower bounds LB = |V_left - (TL,BL)| + |V_right - (TR,BR)| (two v_sad_u16 on packed u16 pairs; lane =
+     * window column cx = l32, one value per vertical displacement) and the survivors: bound <= threshold, appended to
+     * the tile's pool.  Every wave owns a segment of the pool (2 macroblocks x T3_CAP entries) and compacts into it with
+     * wave ballots: no atomics, no pool-full case.
+     *   fast pass: bounds are tested as they are computed, four rows at a time, against the start points' threshold --
+     *     nothing is kept, most groups hold no survivor;
+     *   second pass, only in a wave one of whose macroblocks kept more than T3_RETRY survivors (the start points were
+     *     poor: new content, the first P picture of a GOP): the bounds are computed again and kept, the candidate with
+     *     the SMALLEST bound is evaluated as a third start point, and the segment is rebuilt against the tighter
+     *     threshold.
+     * A macroblock with more than T3_CAP survivors after that is listed for the exhaustive search (k_me_fix). ---- */
     uint32_t mycnt = 0; /* survivors of this lane's macroblock besides the start points */
     {
-        const int thrk = mb_valid ? (int)((thr << 6) | 63u) : -1; /* (pk < 2^22: the signed compare never passes -1) */
         const uint32_t tag = (uint32_t)hw << 11;
         const uint32_t lt = (1u << l32) - 1u;
         uint32_t *seg = s_pool + (tid >> 6) * (2 * T3_CAP);
@@ -358,32 +321,114 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             wcnt += (uint32_t)__popcll(pb);
             mycnt += (uint32_t)__popc(hm);
         };
+        const uint32_t *colp = v8 + row0 * T2_SU + col0 + l32;
+        uint32_t lbx0, lbx1 = 0xffffffffu; /* column cx = 32: lane l32 owns cy = l32, lane 0 also cy = 32 */
+        {
+            const uint32_t *colx = v8 + row0 * T2_SU + col0 + 32;
+            lbx0 = __builtin_amdgcn_sad_u16(colx[l32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colx[l32 * T2_SU], cleft, 0u));
+            if (l32 == 0) lbx1 = __builtin_amdgcn_sad_u16(colx[32 * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colx[32 * T2_SU], cleft, 0u));
+        }
+        bool again = S.me_fast == 0;
+        if (S.me_fast) {
+            const int thrs = mb_valid ? (int)thr : -1; /* (bounds < 2^17: the signed compare never passes -1) */
 #pragma unroll
-        for (int g0 = 0; g0 < 33; g0 += 4) {
-            int gmin = (int)pk[g0];
+            for (int g0 = 0; g0 < 33; g0 += 4) {
+                uint32_t lb[4];
 #pragma unroll
-            for (int j = 1; j < 4; j++)
-                if (g0 + j < 33) gmin = min(gmin, (int)pk[g0 + j]);
-            if (__ballot(gmin <= thrk) == 0ull) continue;
+                for (int j = 0; j < 4; j++)
+                    lb[j] = g0 + j < 33 ? __builtin_amdgcn_sad_u16(colp[(g0 + j) * T2_SU + 8], cright,
+                                                                   __builtin_amdgcn_sad_u16(colp[(g0 + j) * T2_SU], cleft, 0u))
+                                        : 0x7fffffffu;
+                const int gmin = (int)min(min(lb[0], lb[1]), min(lb[2], lb[3]));
+                if (__ballot(gmin <= thrs) == 0ull) continue;
 #pragma unroll
-            for (int cy = g0; cy < (g0 + 4 < 33 ? g0 + 4 : 33); cy++) {
-                const bool hit = (int)pk[cy] <= thrk;
-                if (__ballot(hit) != 0ull) {
-                    /* the rare path: the empty asm keeps its arithmetic inside the branch (hoisted, the 33 copies of
-                     * it cost 60+ registers) */
-                    uint32_t pv = pk[cy];
-                    asm volatile("" : "+v"(pv));
-                    const uint32_t ci = (pv & 63u) * 33u + (uint32_t)l32;
-                    append(hit && ci != (uint32_t)ci_p && ci != (uint32_t)ai, ((pv >> 6) << 15) | tag | ci);
+                for (int j = 0; j < 4; j++) {
+                    if (g0 + j >= 33) break;
+                    const bool hit = (int)lb[j] <= thrs;
+                    if (__ballot(hit) != 0ull) {
+                        const uint32_t ci = (uint32_t)((g0 + j) * 33) + (uint32_t)l32;
+                        append(hit && ci != (uint32_t)ci_p && ci != (uint32_t)ci_z, (lb[j] << 15) | tag | ci);
+                    }
                 }
             }
+            {   /* column cx = 32 */
+                const bool hit0 = (int)lbx0 <= thrs, hit1 = l32 == 0 && (int)lbx1 <= thrs;
+                if (__ballot(hit0 || hit1) != 0ull) {
+                    const uint32_t ci0 = (uint32_t)(l32 * 33 + 32), ci1 = (uint32_t)(32 * 33 + 32);
+                    append(hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ci_z, (lbx0 << 15) | tag | ci0);
+                    append(hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ci_z, (lbx1 << 15) | tag | ci1);
+                }
+            }
+            again = __ballot(mycnt > T3_RETRY) != 0ull;
         }
-        {   /* column cx = 32 */
-            const bool hit0 = mb_valid && lbx0 <= thr, hit1 = mb_valid && lbx1 <= thr;
-            if (__ballot(hit0 || hit1) != 0ull) {
-                const uint32_t ci0 = (uint32_t)(l32 * 33 + 32), ci1 = (uint32_t)(32 * 33 + 32);
-                append(hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ai, (lbx0 << 15) | tag | ci0);
-                append(hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ai, (lbx1 << 15) | tag | ci1);
+        if (again) {
+            /* packed bounds pk = LB << 6 | cy, one register per vertical displacement */
+            uint32_t pk[33];
+            /* batches of 6 rows: at most 12 sums in flight (one batch of 33 would hold 66 registers and the sixth wave) */
+#pragma unroll
+            for (int c0 = 0; c0 < 33; c0 += 6) {
+#pragma unroll
+                for (int cy = c0; cy < (c0 + 6 < 33 ? c0 + 6 : 33); cy++) {
+                    const uint32_t lb =
+                        __builtin_amdgcn_sad_u16(colp[cy * T2_SU + 8], cright, __builtin_amdgcn_sad_u16(colp[cy * T2_SU], cleft, 0u));
+                    pk[cy] = (lb << 6) | (uint32_t)cy;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            /* candidate with the smallest bound (any of them on ties) */
+            int ai, acx, acy;
+            {
+                uint32_t m = pk[0];
+#pragma unroll
+                for (int cy = 1; cy < 33; cy += 2) m = min(min(m, pk[cy]), pk[cy + 1]);
+                uint32_t lmin = ((m >> 6) << 12) | ((m & 63u) << 6) | (uint32_t)l32; /* LB << 12 | cy << 6 | cx */
+                lmin = min(lmin, (lbx0 << 12) | ((uint32_t)l32 << 6) | 32u);
+                if (l32 == 0) lmin = min(lmin, (lbx1 << 12) | (32u << 6) | 32u);
+                const uint32_t w = half_min32(lmin, lane);
+                acy = (int)((w >> 6) & 63u), acx = (int)(w & 63u);
+                ai = acy * 33 + acx;
+            }
+            {
+                const uint32_t rank_a = rank[ai];
+                const uint32_t a = me3_quarter_sad(s_win, s_cur, col0, row0, lane, acx, acy); /* both quarters of a half: the same candidate */
+                const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), q2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47);
+                const uint32_t sad_a = lane < 32 ? q0 : q2;
+                thr = min(thr, sad_a);
+                if (l32 == 0) {
+                    const unsigned long long ka = ((unsigned long long)((sad_a << 11) | rank_a) << 11) | (uint32_t)ai;
+                    const unsigned long long cur_best = s_best[hw];
+                    s_best[hw] = ka < cur_best ? ka : cur_best;
+                }
+            }
+            wcnt = 0, mycnt = 0; /* the segment is rebuilt */
+            const int thrk = mb_valid ? (int)((thr << 6) | 63u) : -1; /* (pk < 2^23: the signed compare never passes -1) */
+#pragma unroll
+            for (int g0 = 0; g0 < 33; g0 += 4) {
+                int gmin = (int)pk[g0];
+#pragma unroll
+                for (int j = 1; j < 4; j++)
+                    if (g0 + j < 33) gmin = min(gmin, (int)pk[g0 + j]);
+                if (__ballot(gmin <= thrk) == 0ull) continue;
+#pragma unroll
+                for (int cy = g0; cy < (g0 + 4 < 33 ? g0 + 4 : 33); cy++) {
+                    const bool hit = (int)pk[cy] <= thrk;
+                    if (__ballot(hit) != 0ull) {
+                        /* the rare path: the empty asm keeps its arithmetic inside the branch (hoisted, the 33 copies of
+                         * it cost 60+ registers) */
+                        uint32_t pv = pk[cy];
+                        asm volatile("" : "+v"(pv));
+                        const uint32_t ci = (pv & 63u) * 33u + (uint32_t)l32;
+                        append(hit && ci != (uint32_t)ci_p && ci != (uint32_t)ci_z && ci != (uint32_t)ai, ((pv >> 6) << 15) | tag | ci);
+                    }
+                }
+            }
+            {   /* column cx = 32 */
+                const bool hit0 = mb_valid && lbx0 <= thr, hit1 = mb_valid && lbx1 <= thr;
+                if (__ballot(hit0 || hit1) != 0ull) {
+                    const uint32_t ci0 = (uint32_t)(l32 * 33 + 32), ci1 = (uint32_t)(32 * 33 + 32);
+                    append(hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ci_z && ci0 != (uint32_t)ai, (lbx0 << 15) | tag | ci0);
+                    append(hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ci_z && ci1 != (uint32_t)ai, (lbx1 << 15) | tag | ci1);
+                }
             }
         }
         if (l32 == 0 && mycnt > T3_CAP) s_ovf[hw] = 1;
@@ -446,7 +491,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
     }
     }
-    }
     /* ---- P5: the luma transform of the tile's macroblocks, straight from the LDS copies the search used: current samples
      * from s_cur, prediction from the window at the winning displacement -> residual, 4x4 transform, quantisation,
      * dequantisation, inverse transform, reconstruction, levels (venc_inter2.hip luma_block_code).  16 macroblocks x 16
@@ -456,9 +500,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * (spec/CODEC.md section 1a; one table load -- the division of the rule is done once per picture, in k_me_fix) */
     venc_qparams ql5 = g.ql, qc5 = g.qc;
     if (RC) {
-        const int qp5 = S.rc_history ? B.qp_cur[item] : S.qp_base;
-        ql5 = B.qtab[qp5];
-        qc5 = B.qtab[venc_chroma_qp(qp5)];
+        const int qp5 = __builtin_amdgcn_readfirstlane(S.rc_history ? B.qp_cur[item] : S.qp_base); /* uniform: scalar table loads */
+        ql5 = qparams_uniform(B.qtab + qp5);
+        qc5 = qparams_uniform(B.qtab + venc_chroma_qp(qp5));
         if (threadIdx.x >= 448) { /* wave 7 has nothing to do in P5: this tile's share of the picture's SAD sum, one atomic per block */
             const int l7 = threadIdx.x - 448;
             uint32_t sad = 0;
