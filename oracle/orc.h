@@ -54,6 +54,7 @@ typedef struct {
                             GOP-sharded run reproduce the single-encoder stream */
     int rc_mode;         /* 0: fixed QP; 1: picture QP by spec/CODEC.md section 1a (qp = the base QP) */
     int intra_modes;     /* 0: Intra16x16 DC prediction only; 1: vertical / horizontal / DC chosen by SAD (spec/CODEC.md section 3) */
+    int subpel;          /* 0: integer-sample vectors; 1: half-sample refinement; 2: half then quarter (spec/CODEC.md section 2a) */
 } orc_params;
 
 typedef struct {
@@ -84,7 +85,8 @@ int orc_enc_import_rows(orc_enc *e, int mb_row0, int mb_row1, const uint8_t *y, 
 /* Introspection of the last encoded frame (for kernel-level parity tests). */
 int orc_enc_mb_width(const orc_enc *e);
 int orc_enc_mb_height(const orc_enc *e);
-const int8_t *orc_enc_mv(const orc_enc *e);        /* [mb][2] = dx,dy integer pel */
+const int8_t *orc_enc_mv(const orc_enc *e);        /* [mb][2] = dx,dy integer pel (the full search's result) */
+const int8_t *orc_enc_mvq(const orc_enc *e);       /* [mb][2] the coded vector in quarter-sample units (4 * mv without refinement) */
 const uint16_t *orc_enc_sad(const orc_enc *e);     /* [mb] best SAD (P frames) */
 const int16_t *orc_enc_levels(const orc_enc *e);   /* [mb][27][16] */
 const uint32_t *orc_enc_mb_bits(const orc_enc *e); /* [mb] bits of macroblock_layer (+skip_run) */
@@ -101,6 +103,8 @@ int orc_me_rank(int dx, int dy);                            /* tie-break rank, 0
 /* picture QP under rate control (spec/CODEC.md section 1a); have_history: the previous picture was a P picture of the same GOP */
 int orc_rc_qp(int base_qp, int is_idr, int have_history, uint64_t prev_sad_sum, int nmb);
 int orc_enc_picture_qp(const orc_enc *e);                   /* QP of the last encoded picture */
+/* luma prediction block at (xq, yq) quarter-sample units, 8.4.2.2.1 with clamped coordinates (orc_interp.h); dst is bw wide */
+void orc_luma_interp(const uint8_t *ref, int stride, int w, int h, int xq, int yq, int bw, int bh, uint8_t *dst);
 /* CAVLC residual block; coef[] in scan order; returns number of bits appended */
 int orc_cavlc_block_bits(const int16_t *coef, int max_coef, int nC, uint8_t *out, size_t cap);
 /* emulation prevention: returns output size */

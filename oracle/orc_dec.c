@@ -15,6 +15,7 @@
  * are decoded by table search, transforms follow the spec equations literally.
  */
 #include "orc.h"
+#include "orc_interp.h"
 #include "orc_tables.h"
 
 #include <stdio.h>
@@ -553,13 +554,13 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
                 /* P_Skip (8.4.1.1): the vector is zero when A or B is missing or has a zero vector (every coded
                  * neighbour here is a P macroblock with refIdx 0), else the 16x16 median prediction; no residual */
                 if (!aA || !aB || (ax == 0 && ay == 0) || (bx_ == 0 && by_ == 0)) px = py = 0;
-                mvx = 4 * px, mvy = 4 * py;
+                mvx = px, mvy = py;
             } else {
-                mvx = br_se(b) + 4 * px, mvy = br_se(b) + 4 * py;
-                if ((mvx & 3) || (mvy & 3)) FAIL(d, "sub-pel mv unsupported");
+                mvx = br_se(b) + px, mvy = br_se(b) + py; /* quarter-sample units throughout */
+                if (mvx < -127 || mvx > 127 || mvy < -127 || mvy > 127) FAIL(d, "vector out of this decoder's range");
             }
-            d->mv[2 * mb] = (int8_t)(mvx / 4);
-            d->mv[2 * mb + 1] = (int8_t)(mvy / 4);
+            d->mv[2 * mb] = (int8_t)mvx;
+            d->mv[2 * mb + 1] = (int8_t)mvy;
             if (!skip) {
                 int code = (int)br_ue(b);
                 if (code > 47) FAIL(d, "bad cbp code");
@@ -568,11 +569,10 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             }
             /* prediction with coordinate clamping */
             uint8_t predl[256], pred[2][64];
-            int dx = mvx >> 2, dy = mvy >> 2;
-            for (int y = 0; y < 16; y++)
-                for (int x = 0; x < 16; x++)
-                    predl[16 * y + x] = d->ref[0][(size_t)clampi(my * 16 + y + dy, 0, d->ch - 1) * d->cw +
-                                                   clampi(mx * 16 + x + dx, 0, d->cw - 1)];
+            {   /* luma: 8.4.2.2.1, integer, half- and quarter-sample positions (orc_interp.h) */
+                const orc_plane rp = {d->ref[0], d->cw, d->cw, d->ch};
+                orc_luma_pred_block(&rp, 4 * mx * 16 + mvx, 4 * my * 16 + mvy, 16, 16, predl, 16);
+            }
             int xf = mvx & 7, yf = mvy & 7;
             for (int p = 0; p < 2; p++)
                 for (int y = 0; y < 8; y++)

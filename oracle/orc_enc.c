@@ -12,6 +12,7 @@
  * transform) -> quantisation -> zig-zag / run-level (CAVLC) -> reconstruction.
  */
 #include "orc.h"
+#include "orc_interp.h"
 #include "orc_tables.h"
 
 #include <stdlib.h>
@@ -318,7 +319,8 @@ struct orc_enc {
     long frame_idx;
     int frame_num, idr_count;
     int *slice_rows;
-    int8_t *mv;
+    int8_t *mv;  /* [mb][2] integer-sample vector of the full search */
+    int8_t *mvq; /* [mb][2] the coded vector in quarter-sample units: 4 * mv, or refined (spec/CODEC.md section 2a) */
     uint16_t *sad;
     int16_t *levels;
     uint32_t *mb_bits;
@@ -385,6 +387,7 @@ orc_enc *orc_enc_open(const orc_params *p) {
         e->slice_rows[e->p.n_slices] = r;
     }
     e->mv = (int8_t *)calloc((size_t)nmb * 2, 1);
+    e->mvq = (int8_t *)calloc((size_t)nmb * 2, 1);
     e->sad = (uint16_t *)calloc((size_t)nmb, 2);
     e->levels = (int16_t *)calloc((size_t)nmb * ORC_MB_COEFS, 2);
     e->mb_bits = (uint32_t *)calloc((size_t)nmb, 4);
@@ -427,6 +430,7 @@ void orc_enc_close(orc_enc *e) {
     free(e->esc_buf);
     free(e->slice_rows);
     free(e->mv);
+    free(e->mvq);
     free(e->sad);
     free(e->levels);
     free(e->mb_bits);
@@ -443,6 +447,7 @@ int orc_enc_picture_qp(const orc_enc *e) { return e->qp_cur; }
 int orc_enc_mb_width(const orc_enc *e) { return e->mbw; }
 int orc_enc_mb_height(const orc_enc *e) { return e->mbh; }
 const int8_t *orc_enc_mv(const orc_enc *e) { return e->mv; }
+const int8_t *orc_enc_mvq(const orc_enc *e) { return e->mvq; }
 const uint16_t *orc_enc_sad(const orc_enc *e) { return e->sad; }
 const int16_t *orc_enc_levels(const orc_enc *e) { return e->levels; }
 const uint32_t *orc_enc_mb_bits(const orc_enc *e) { return e->mb_bits; }
@@ -500,7 +505,49 @@ static void me_mb(orc_enc *e, int mx, int my) {
     int mb = my * e->mbw + mx;
     e->mv[2 * mb] = (int8_t)bdx;
     e->mv[2 * mb + 1] = (int8_t)bdy;
+    e->mvq[2 * mb] = (int8_t)(4 * bdx);
+    e->mvq[2 * mb + 1] = (int8_t)(4 * bdy);
     e->sad[mb] = (uint16_t)(best >> 11);
+}
+
+/* ---- sub-sample refinement around the full search's vector (spec/CODEC.md section 2a): a half-sample stage (the vector
+ * and its eight neighbours at +-2 quarter units), then with subpel = 2 a quarter-sample stage around that stage's winner
+ * (+-1).  A stage's winner is the minimum of (SAD << 4) | index, index 0 = the stage's centre, 1..8 = the neighbours in
+ * raster order; predictions by 8.4.2.2.1 (orc_interp.h).  Behind x264_encoder_encode (av_encode.c:970) this is what the
+ * reference's presets (av_encode.c:365) ask libx264 for as subpixel refinement. ---- */
+static void subpel_mb(orc_enc *e, int mx, int my) {
+    const int mb = my * e->mbw + mx;
+    const uint8_t *cur = e->cur[0] + (size_t)(my * 16) * e->cw + mx * 16;
+    const orc_plane ref = {e->refp[0] + (size_t)LPAD * e->refp_stride[0] + LPAD, e->refp_stride[0], e->cw, e->ch};
+    int cx = e->mvq[2 * mb], cy = e->mvq[2 * mb + 1];
+    uint32_t csad = e->sad[mb];
+    for (int stage = 0; stage < e->p.subpel && stage < 2; stage++) {
+        const int step = stage == 0 ? 2 : 1;
+        uint32_t best = csad << 4; /* index 0: the centre, whose SAD is known */
+        int bx = cx, by = cy, idx = 0;
+        for (int ey = -1; ey <= 1; ey++)
+            for (int ex = -1; ex <= 1; ex++) {
+                if (!ex && !ey) continue;
+                idx++;
+                const int qx = cx + step * ex, qy = cy + step * ey;
+                uint32_t sad = 0;
+                for (int y = 0; y < 16; y++)
+                    for (int x = 0; x < 16; x++)
+                        sad += (uint32_t)abs((int)cur[(size_t)y * e->cw + x] - orc_luma_qpel(&ref, 4 * (mx * 16 + x) + qx, 4 * (my * 16 + y) + qy));
+                const uint32_t key = (sad << 4) | (uint32_t)idx;
+                if (key < best) best = key, bx = qx, by = qy;
+            }
+        cx = bx, cy = by, csad = best >> 4;
+    }
+    e->mvq[2 * mb] = (int8_t)cx;
+    e->mvq[2 * mb + 1] = (int8_t)cy;
+    e->sad[mb] = (uint16_t)csad;
+}
+
+/* stand-alone interpolation (unit tests): bw x bh luma prediction block at (xq, yq) quarter-sample units of a w x h plane */
+void orc_luma_interp(const uint8_t *ref, int stride, int w, int h, int xq, int yq, int bw, int bh, uint8_t *dst) {
+    const orc_plane r = {ref, stride, w, h};
+    orc_luma_pred_block(&r, xq, yq, bw, bh, dst, bw);
 }
 
 static inline uint8_t clip_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
@@ -576,6 +623,7 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
     int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     memset(lv, 0, ORC_MB_COEFS * sizeof(int16_t));
     e->mv[2 * mb] = e->mv[2 * mb + 1] = 0;
+    e->mvq[2 * mb] = e->mvq[2 * mb + 1] = 0;
     e->sad[mb] = 0;
 
     /* luma DC prediction (8.3.3.3) */
@@ -709,12 +757,21 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
 static void code_mb_inter(orc_enc *e, int mx, int my) {
     int mb = my * e->mbw + mx;
     int qp = e->qp_cur;
-    int dx = e->mv[2 * mb], dy = e->mv[2 * mb + 1];
+    const int qx = e->mvq[2 * mb], qy = e->mvq[2 * mb + 1]; /* quarter-sample units */
     int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     memset(lv, 0, ORC_MB_COEFS * sizeof(int16_t));
 
-    int rs = e->refp_stride[0];
-    const uint8_t *ref = e->refp[0] + (size_t)(my * 16 + dy + LPAD) * rs + mx * 16 + dx + LPAD;
+    /* luma prediction: the reference block at the vector, interpolated (8.4.2.2.1) when the vector is fractional */
+    uint8_t predl[256];
+    int rs = 16;
+    const uint8_t *ref = predl;
+    if ((qx | qy) & 3) {
+        const orc_plane rp = {e->refp[0] + (size_t)LPAD * e->refp_stride[0] + LPAD, e->refp_stride[0], e->cw, e->ch};
+        orc_luma_pred_block(&rp, 4 * mx * 16 + qx, 4 * my * 16 + qy, 16, 16, predl, 16);
+    } else {
+        rs = e->refp_stride[0];
+        ref = e->refp[0] + (size_t)(my * 16 + (qy >> 2) + LPAD) * rs + mx * 16 + (qx >> 2) + LPAD;
+    }
     const uint8_t *cur = e->cur[0] + (size_t)(my * 16) * e->cw + mx * 16;
     uint8_t *rec = e->rec[0] + (size_t)(my * 16) * e->cw + mx * 16;
     int cbpl = 0;
@@ -742,7 +799,7 @@ static void code_mb_inter(orc_enc *e, int mx, int my) {
         if (n) cbpl |= 1 << (blk >> 2);
     }
     /* chroma MC (8.4.2.2.2): mvC = luma mv in 1/8 chroma sample units */
-    int mvx = 4 * dx, mvy = 4 * dy;
+    int mvx = qx, mvy = qy;
     int xi = mvx >> 3, yi = mvy >> 3, xf = mvx & 7, yf = mvy & 7;
     for (int plane = 1; plane <= 2; plane++) {
         int cst = e->refp_stride[plane];
@@ -814,13 +871,13 @@ static void predict_mv(const orc_enc *e, int mx, int my, int srow, int *px, int 
     int mb = my * e->mbw + mx;
     int aA = mx > 0, aB = my > srow, aC = my > srow && mx + 1 < e->mbw, aD = my > srow && mx > 0;
     int ax = 0, ay = 0, bx = 0, by = 0, cx = 0, cy = 0;
-    if (aA) ax = e->mv[2 * (mb - 1)], ay = e->mv[2 * (mb - 1) + 1];
-    if (aB) bx = e->mv[2 * (mb - e->mbw)], by = e->mv[2 * (mb - e->mbw) + 1];
+    if (aA) ax = e->mvq[2 * (mb - 1)], ay = e->mvq[2 * (mb - 1) + 1];
+    if (aB) bx = e->mvq[2 * (mb - e->mbw)], by = e->mvq[2 * (mb - e->mbw) + 1];
     if (aC)
-        cx = e->mv[2 * (mb - e->mbw + 1)], cy = e->mv[2 * (mb - e->mbw + 1) + 1];
+        cx = e->mvq[2 * (mb - e->mbw + 1)], cy = e->mvq[2 * (mb - e->mbw + 1) + 1];
     else if (aD) {
         aC = 1;
-        cx = e->mv[2 * (mb - e->mbw - 1)], cy = e->mv[2 * (mb - e->mbw - 1) + 1];
+        cx = e->mvq[2 * (mb - e->mbw - 1)], cy = e->mvq[2 * (mb - e->mbw - 1) + 1];
     }
     if (!aB && !aC && aA) {
         *px = ax;
@@ -871,10 +928,10 @@ static int mb_is_skip(const orc_enc *e, int mx, int my, int srow) {
     if (e->mb_cbp[mb] != 0) return 0;
     int sx = 0, sy = 0;
     if (mx > 0 && my > srow) {
-        const int8_t *a = e->mv + 2 * (mb - 1), *bb = e->mv + 2 * (mb - e->mbw);
+        const int8_t *a = e->mvq + 2 * (mb - 1), *bb = e->mvq + 2 * (mb - e->mbw);
         if (!((a[0] == 0 && a[1] == 0) || (bb[0] == 0 && bb[1] == 0))) predict_mv(e, mx, my, srow, &sx, &sy);
     }
-    return e->mv[2 * mb] == sx && e->mv[2 * mb + 1] == sy;
+    return e->mvq[2 * mb] == sx && e->mvq[2 * mb + 1] == sy;
 }
 static void write_mb_inter(orc_enc *e, bw_t *b, int mx, int my, int srow, int skip_run) {
     int mb = my * e->mbw + mx;
@@ -884,8 +941,8 @@ static void write_mb_inter(orc_enc *e, bw_t *b, int mx, int my, int srow, int sk
     predict_mv(e, mx, my, srow, &px, &py);
     bw_ue(b, (uint32_t)skip_run); /* mb_skip_run: P_Skip macroblocks since the previous coded one */
     bw_ue(b, 0); /* mb_type P_L0_16x16 */
-    bw_se(b, 4 * (e->mv[2 * mb] - px));
-    bw_se(b, 4 * (e->mv[2 * mb + 1] - py));
+    bw_se(b, e->mvq[2 * mb] - px); /* mvd_l0 in quarter-sample units */
+    bw_se(b, e->mvq[2 * mb + 1] - py);
     bw_ue(b, e->cbp_to_code[cbp]);
     if (cbp) bw_se(b, 0); /* mb_qp_delta */
     for (int q = 0; q < 4; q++)
@@ -1044,9 +1101,14 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
 #pragma omp parallel for schedule(dynamic, 1)
         for (int my = e->slice_rows[e->band_s0]; my < e->slice_rows[e->band_s1]; my++)
             for (int mx = 0; mx < e->mbw; mx++) me_mb(e, mx, my);
-        uint64_t sum = 0;
+        uint64_t sum = 0; /* (the rate control reads the full search's SADs, before any refinement) */
         for (int i = 0; i < e->mbw * e->mbh; i++) sum += e->sad[i];
         e->prev_sad_sum = sum;
+        if (e->p.subpel) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int my = e->slice_rows[e->band_s0]; my < e->slice_rows[e->band_s1]; my++)
+                for (int mx = 0; mx < e->mbw; mx++) subpel_mb(e, mx, my);
+        }
     }
     e->prev_was_p = !idr;
 #pragma omp parallel for schedule(dynamic, 1)

@@ -18,7 +18,7 @@ MAX_NALS = 512
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "keyint", "fps_num", "fps_den",
-                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode", "intra_modes")]
+                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode", "intra_modes", "subpel")]
 
 
 class OrcNal(C.Structure):
@@ -26,7 +26,7 @@ class OrcNal(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orc_enc.c", "orc_dec.c", "orc.h", "orc_tables.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_enc.c", "orc_dec.c", "orc.h", "orc_interp.h", "orc_tables.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
@@ -47,7 +47,7 @@ def lib():
         L.orc_enc_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                      C.c_void_p, C.c_size_t, C.POINTER(OrcNal), C.POINTER(C.c_int),
                                      C.POINTER(C.c_int)]
-        for name, rt in (("orc_enc_mv", C.POINTER(C.c_int8)), ("orc_enc_sad", C.POINTER(C.c_uint16)),
+        for name, rt in (("orc_enc_mv", C.POINTER(C.c_int8)), ("orc_enc_mvq", C.POINTER(C.c_int8)), ("orc_enc_sad", C.POINTER(C.c_uint16)),
                          ("orc_enc_levels", C.POINTER(C.c_int16)), ("orc_enc_mb_bits", C.POINTER(C.c_uint32)),
                          ("orc_enc_slice_rows", C.POINTER(C.c_int))):
             getattr(L, name).restype = rt
@@ -91,11 +91,12 @@ class Frame:
 
 
 class Encoder:
-    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False, intra_modes=False):
+    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False, intra_modes=False, subpel=0):
         """rc: picture QP by spec/CODEC.md section 1a (the CRF approximation), qp = its base; else fixed QP.
-        intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only."""
+        intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only.
+        subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a)."""
         self.L = lib()
-        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(bool(intra_modes)))
+        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(bool(intra_modes)), int(subpel))
         self.h = self.L.orc_enc_open(C.byref(self.params))
         if not self.h:
             raise ValueError("orc_enc_open rejected the parameters")
@@ -148,6 +149,10 @@ class Encoder:
 
     def mv(self):
         return np.ctypeslib.as_array(self.L.orc_enc_mv(self.h), (self.nmb, 2)).copy()
+
+    def mvq(self):
+        """the coded vectors in quarter-sample units (4 * mv() without sub-sample refinement)"""
+        return np.ctypeslib.as_array(self.L.orc_enc_mvq(self.h), (self.nmb, 2)).copy()
 
     def sad(self):
         return np.ctypeslib.as_array(self.L.orc_enc_sad(self.h), (self.nmb,)).copy()
@@ -203,6 +208,17 @@ class Decoder:
 
     def size(self):
         return (self.L.orc_dec_crop_width(self.h), self.L.orc_dec_crop_height(self.h))
+
+
+def luma_interp(plane, xq, yq, bw, bh):
+    """bw x bh luma prediction block whose top-left sample sits at (xq, yq) quarter-sample units of `plane`"""
+    plane = np.ascontiguousarray(plane, dtype=np.uint8)
+    out = np.empty((bh, bw), dtype=np.uint8)
+    L = lib()
+    L.orc_luma_interp.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.orc_luma_interp.restype = None
+    L.orc_luma_interp(plane.ctypes.data, plane.strides[0], plane.shape[1], plane.shape[0], xq, yq, bw, bh, out.ctypes.data)
+    return out
 
 
 def escape(rbsp):
