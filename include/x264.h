@@ -109,6 +109,11 @@ typedef struct x264_param_t {
         /* Intra16x16 prediction of I pictures: 1 (x264_param_default_preset's default, like libx264's presets) = vertical /
          * horizontal / DC chosen per macroblock by SAD; 0 = DC only (the codec definition of round 1, what bench.py measures) */
         int i_intra_modes;
+        /* sub-sample refinement of the motion vectors (libx264's analyse.i_subpel_refine, which the reference leaves to its
+         * preset, av_encode.c:365): 0 = integer-sample vectors (what bench.py measures), 1 = half-sample, 2 = half- then
+         * quarter-sample stage (x264_param_default_preset's default for every preset but "ultrafast", as in libx264).
+         * Slice-band encoders run with 0. */
+        int i_subpel;
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;

@@ -48,7 +48,7 @@ def build(verbose=False):
 # ----------------------------------------------------------------------------- C-ABI structs
 class VencConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "max_items", "in_slots", "out_slots",
-                                       "device", "rc_mode", "intra_modes")]
+                                       "device", "rc_mode", "intra_modes", "subpel")]
 
 
 class VencSlice(C.Structure):
@@ -80,7 +80,7 @@ class _Hip(C.Structure):
     _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int),
                 ("i_slice_first", C.c_int), ("i_slice_count", C.c_int), ("pf_exchange", EXCHANGE_FN),
                 ("p_exchange_user", C.c_void_p), ("i_rccl_world", C.c_int), ("i_rccl_rank", C.c_int),
-                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128), ("i_intra_modes", C.c_int)]
+                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128), ("i_intra_modes", C.c_int), ("i_subpel", C.c_int)]
 
 
 class X264Param(C.Structure):
@@ -334,12 +334,13 @@ def synth_frame(width, height, frame_index, seed=0x1234ABCD):
 class Engine:
     """One encoder context on one GPU: frame slots in, slice RBSPs out."""
 
-    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None, rc=False, intra_modes=False):
+    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None, rc=False, intra_modes=False, subpel=0):
         """lib: a library bound with bind_hip() instead of the product library (tests load the legacy build this way).
         rc: picture QP by spec/CODEC.md section 1a (qp = the base) instead of fixed QP.
-        intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only."""
+        intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only.
+        subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a)."""
         self.L = lib if lib is not None else hip_lib()
-        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)), int(bool(intra_modes)))
+        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)), int(bool(intra_modes)), int(subpel))
         h = C.c_void_p()
         rc = self.L.venc_open(C.byref(self.cfg), C.byref(h))
         if rc != 0:
@@ -444,7 +445,8 @@ class Engine:
                   3: ((self.nmb,), np.uint32), 4: ((ch, cw), np.uint8), 5: ((ch // 2, cw // 2), np.uint8),
                   6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32),
                   8: ((ch + 25, (cw + 32) & ~15), np.uint32), 9: ((self.nmb,), np.uint8), 10: ((self.nmb,), np.uint8),
-                  11: ((8,), np.uint64), 12: ((self.nmb, 32), np.int32), 13: ((self.nmb, 128), np.int32)}
+                  11: ((8,), np.uint64), 12: ((self.nmb, 32), np.int32), 13: ((self.nmb, 128), np.int32),
+                  14: ((self.nmb,), np.uint32)}
         shape, dt = shapes[what]
         a = np.empty(shape, dt)
         self._ok(self.L.venc_debug_read(self.h, what, item, a.ctypes.data, a.nbytes), "venc_debug_read")
@@ -455,6 +457,11 @@ class Engine:
         dx = (m & 0xff).astype(np.int8)
         dy = ((m >> 8) & 0xff).astype(np.int8)
         return np.stack([dx, dy], axis=1), (m >> 16).astype(np.uint16)
+
+    def mvq_sad(self, item=0):
+        """the coded vectors in quarter samples and their SADs (engines with sub-sample refinement)"""
+        m = self.debug(14, item)
+        return np.stack([(m & 0xff).astype(np.int8), ((m >> 8) & 0xff).astype(np.int8)], axis=1), (m >> 16).astype(np.uint16)
 
 
 # ----------------------------------------------------------------------------- X264Encoder (x264.h)
@@ -470,7 +477,7 @@ class X264Encoder:
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
                  tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0,
-                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False):
+                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0):
         """slice_first / slice_count / exchange: slice-parallel multi-GPU mode (include/x264.h, hip extension);
         exchange(engine_view, n_items) is called after every picture that a P picture follows.
         rccl = (world, rank, id_bytes, halo_rows): the engine does the exchange itself in C over RCCL
@@ -494,6 +501,7 @@ class X264Encoder:
         # Intra16x16 V / H / DC by SAD: the C API's preset default is on; this mirror defaults to the DC-only codec
         # definition that bench.py and the golden fixtures are frozen on
         p.hip.i_intra_modes = int(bool(intra_modes))
+        p.hip.i_subpel = int(subpel)  # (likewise: the C API's presets refine to quarter samples)
         if rccl is not None:
             world, rank, ident, halo = rccl
             p.hip.i_rccl_world, p.hip.i_rccl_rank, p.hip.i_halo_rows = world, rank, halo

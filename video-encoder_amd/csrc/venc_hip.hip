@@ -24,6 +24,7 @@
 #include "venc_me.hip"
 #endif
 #include "venc_me3.hip"
+#include "venc_subpel.hip"
 #include "venc_cavlc_p.hip"
 #include "venc_intra2.hip"
 #include "venc_synth.h"
@@ -171,9 +172,9 @@ struct venc_ctx {
     int prof_n, prof_cap, prof_open;
 };
 
-enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_COUNT };
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_SUBPEL, KID_COUNT };
 /* "k_inter" = k_inter_fused (luma + chroma transforms) */
-static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma"};
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma", "k_subpel"};
 
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
     c->prof_open = 0;
@@ -277,6 +278,8 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
+    (void)hipFree(c->b.pred_luma);
+    (void)hipFree(c->b.mvq);
     (void)hipFree(c->b.stamps);
     (void)hipFree(c->b.fix_count);
     (void)hipFree(c->d_sad_sum);
@@ -352,6 +355,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     fill_qparams(&g.ql, cfg->qp);
     fill_qparams(&g.qc, cfg->qp < 30 ? cfg->qp : h_qpc_hi[cfg->qp - 30]);
     c->cfg.n_slices = g.n_slices;
+    g.subpel = cfg->subpel < 0 ? 0 : cfg->subpel > 2 ? 2 : cfg->subpel;
     c->g_idr = g;
     g.slice_base = g.mbh / g.n_slices;
     g.slice_rem = g.mbh % g.n_slices;
@@ -580,6 +584,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
     OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
+    if (g.subpel) {
+        OPEN_OK(hipMalloc(&b.pred_luma, G * nmb * 256));
+        OPEN_OK(hipMalloc(&b.mvq, (size_t)VENC_RING * G * nmb * 4));
+        OPEN_OK(hipMemset(b.mvq, 0, (size_t)VENC_RING * G * nmb * 4));
+    }
     OPEN_OK(hipMalloc(&b.me_cnt, G * nmb));
     OPEN_OK(hipMemset(b.me_cnt, 0, G * nmb));
     OPEN_OK(hipMalloc(&c->d_slice, GV * g.n_slices * sizeof(venc_slice_out)));
@@ -772,6 +781,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     const int rs = (int)(c->step_no % VENC_RING), rs_prev = (int)((c->step_no + VENC_RING - 1) % VENC_RING);
     b.mvsad = c->b.mvsad + (size_t)rs * GN;
     b.mvsad_prev = c->b.mvsad + (size_t)rs_prev * GN;
+    if (g.subpel) b.mvq = c->b.mvq + (size_t)rs * GN;
     b.levels = c->b.levels + (size_t)rs * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
     if (c->cfg.rc_mode) {
@@ -857,7 +867,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         b.fix_count = c->b.fix_count + (size_t)c->fix_phase * c->b.max_items;
         b.fix_count_next = c->b.fix_count + (size_t)(c->fix_phase ^ 1) * c->b.max_items;
         c->fix_phase ^= 1;
-        const bool fuse = c->fuse_luma && c->me_mode == 0 && !c->inter_legacy;
+        const bool fuse = c->fuse_luma && c->me_mode == 0 && !c->inter_legacy && !g.subpel; /* (refinement sits between search and transform) */
         const int fuse_arg = !fuse ? 0 : c->fuse_luma; /* 1: luma in the search kernels; 2: chroma too */
         if (c->me_mode != 0) HIP_OK(hipMemsetAsync(b.fix_count_next, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
@@ -903,10 +913,17 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         } else
 #endif
         if (!fuse) {
+            if (g.subpel) { /* vectors -> quarter samples, predictions -> B.pred_luma (venc_subpel.hip) */
+                prof_begin(c, KID_SUBPEL, s1);
+                hipLaunchKernelGGL(k_subpel, dim3((band_mbs + 3) / 4, 1, n_items), dim3(256), 0, s1, g, b, S);
+                prof_end(c, s1);
+            }
             /* luma transform and chroma transform: independent blocks of one launch */
             const int n_luma = (band_mbs + 15) / 16, n_chroma = (band_mbs + 31) / 32;
+            venc_bufs bt = b;
+            if (g.subpel) bt.mvsad = b.mvq; /* the refined vectors */
             prof_begin(c, KID_INTER, s1);
-            hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, b, S, n_luma);
+            hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, bt, S, n_luma);
             prof_end(c, s1);
         } else {
             /* The main chain ends here: search + luma transform, the flagged macroblocks' redo.  The next step's search
@@ -968,7 +985,7 @@ static int entropy_flush(venc_ctx *c) {
     const int is_idr = S.is_idr;
     const int band_mbs = S.mb1 - S.mb0, band_slices = S.slice1 - S.slice0;
     venc_bufs b = c->b;
-    b.mvsad = c->b.mvsad + (size_t)rs0 * GN;
+    b.mvsad = (g.subpel && !S.is_idr ? c->b.mvq : c->b.mvsad) + (size_t)rs0 * GN; /* (refined vectors: quarter samples) */
     b.levels = c->b.levels + (size_t)rs0 * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs0 * GN;
     if (c->cfg.rc_mode) b.qp_cur = c->d_qp_ring + (size_t)(c->eb_first_step % VENC_QP_RING) * c->b.max_items;
@@ -1050,6 +1067,10 @@ extern "C" int venc_set_band(venc_ctx *c, int slice_first, int slice_count) {
     if (slice_first == 0 && slice_count == 0) slice_count = c->g.n_slices;
     if (slice_first < 0 || slice_count < 1 || slice_first + slice_count > c->g.n_slices) {
         SET_ERR("venc_set_band: slices [%d, %d) outside 0..%d", slice_first, slice_first + slice_count, c->g.n_slices);
+        return -1;
+    }
+    if (c->g.subpel && slice_count != c->g.n_slices) {
+        SET_ERR("venc_set_band: sub-sample refinement needs the whole picture (a band's halo of 16 rows is three short of the six-tap filter's reach)");
         return -1;
     }
     if (c->cfg.rc_mode && slice_count != c->g.n_slices) {
@@ -1287,7 +1308,14 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
     const size_t lp_off = (size_t)((c->step_no + VENC_RING - 1) % VENC_RING) * c->b.max_items; /* ring slot of the last step */
     const uint8_t *rec = c->b.recon + (size_t)(last_parity * c->b.max_items + item) * c->b.recon_frame_bytes;
     switch (what) {
-        case 0: src = c->b.mvsad + (lp_off + item) * nmb, n = nmb * 4; break;
+        case 0: src = c->b.mvsad + (lp_off + item) * nmb, n = nmb * 4; break; /* the search's vectors, integer samples */
+        case 14: /* the coded vectors in quarter samples (sub-sample refinement) */
+            if (!c->b.mvq) {
+                SET_ERR("venc_debug_read: no refined vectors (subpel = 0)");
+                return -1;
+            }
+            src = c->b.mvq + (lp_off + item) * nmb, n = nmb * 4;
+            break;
         case 1: src = c->b.levels + (lp_off + item) * nmb * VENC_MB_COEFS, n = nmb * VENC_MB_COEFS * 2; break;
         case 2: src = c->b.mbinfo + (lp_off + item) * nmb, n = nmb * sizeof(venc_mbinfo); break;
         case 3: src = c->b.mbnbits + item * nmb, n = nmb * 4; break;

@@ -219,7 +219,12 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
     uint32_t cq[4], pq[4]; /* current and predicted rows, four samples per dword */
     load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, cq);
     const int x0 = px + dx, y0 = py + dy;
-    if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
+    if (g.subpel) {
+        /* the vector is fractional (quarter samples): k_subpel left the macroblock's prediction in B.pred_luma */
+        const uint32_t *pm = (const uint32_t *)(B.pred_luma + ((size_t)item * g.nmb + mb) * 256);
+#pragma unroll
+        for (int y = 0; y < 4; y++) pq[y] = pm[(blk_y(blk) * 4 + y) * 4 + blk_x(blk)];
+    } else if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
         const uint32_t sh = (uint32_t)(x0 & 3);
         const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
 #pragma unroll
@@ -253,8 +258,9 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
     int p[16];
     uint32_t cq[4];
     load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 7) == 0, cq);
-    /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
-    const int x0 = px + (dx >> 1), y0 = py + (dy >> 1);
+    /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4); under sub-sample refinement the
+     * vector arrives in quarter luma = eighth chroma samples */
+    const int x0 = px + (g.subpel ? dx >> 3 : dx >> 1), y0 = py + (g.subpel ? dy >> 3 : dy >> 1);
     const bool fx = (dx & 1) != 0, fy = (dy & 1) != 0;
     /* rows of the reference as packed samples: ra[y] = samples x0..x0+3, rb[y] = x0+1..x0+4 */
     uint32_t ra[5], rb[5];
@@ -284,6 +290,19 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
      * h = A + (fx ? B : A).  The pair sums come straight from the packed rows (one select per ROW between the row and the
      * row one sample on, then byte-select adds); one select, one three-operand add and a shift per sample remain.  No
      * quarter-rate multiplies, no unpacking. */
+    if (g.subpel) {
+        /* any of the 64 fractions: the bilinear formula as it stands (24-bit multiplies) */
+        const int xf = dx & 7, yf = dy & 7;
+        const int wa = (8 - xf) * (8 - yf), wb = xf * (8 - yf), wc = (8 - xf) * yf, wd = xf * yf;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const int A = (int)((ra[y] >> (8 * x)) & 255u), Bv = (int)((rb[y] >> (8 * x)) & 255u);
+                const int Cv = (int)((ra[y + 1] >> (8 * x)) & 255u), D = (int)((rb[y + 1] >> (8 * x)) & 255u);
+                p[4 * y + x] = (VENC_MUL24(wa, A) + VENC_MUL24(wb, Bv) + VENC_MUL24(wc, Cv) + VENC_MUL24(wd, D) + 32) >> 6;
+            }
+    } else {
     int hs[5][4];
 #pragma unroll
     for (int y = 0; y < 5; y++) {
@@ -297,6 +316,7 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
     for (int y = 0; y < 4; y++)
 #pragma unroll
         for (int x = 0; x < 4; x++) p[4 * y + x] = (hs[y][x] + (fy ? hs[y + 1][x] : hs[y][x]) + 2) >> 2;
+    }
 
     int res[16], w[16], lv[16], rr[16], nnz;
 #pragma unroll

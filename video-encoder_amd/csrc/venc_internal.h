@@ -62,6 +62,7 @@ typedef struct {
     int n_slices;
     int slice_base, slice_rem; /* bands: the first slice_rem slices have slice_base+1 MB rows, the rest slice_base */
     int qp;
+    int subpel; /* 0: vectors in integer samples; 1, 2: P pictures refine them (k_subpel) and every vector of the step is in QUARTER samples */
     venc_qparams ql, qc;
 } venc_geom;
 
@@ -137,6 +138,9 @@ typedef struct {
     int *qp_cur;                /* [G] this step's slot of the QP ring (16 steps) */
     int *qp_next;               /* [G] the next step's slot: written by the last block of this step's k_me_fix from the final SAD sum */
     uint32_t *fix_done;         /* [G] k_me_fix blocks that have finished (zero between launches) */
+    uint32_t *mvq;              /* sub-sample refinement: the step's vectors in QUARTER samples (SAD << 16 | qy << 8 | qx), what the
+                                   transform and entropy kernels are handed as `mvsad`; the searches keep their integer vectors */
+    uint8_t *pred_luma;         /* [item][mb][256] sub-sample refinement: the luma prediction of every macroblock at its refined vector */
     const venc_qparams *qtab;   /* [52] quantiser constants of every QP (built by the host at open) */
     uint8_t *out_hdr;           /* device view of the pinned header pool: per slot venc_out_header + slice table */
     size_t out_hdr_stride;

@@ -758,8 +758,8 @@ DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t
     mv_predict(g, mvs, mb, mx, aL, aT, pxv, pyv, z);
     venc_bs_ue(bs, skip_run); /* mb_skip_run: P_Skip macroblocks since the previous coded one */
     venc_bs_ue(bs, 0); /* mb_type P_L0_16x16 */
-    venc_bs_se(bs, 4 * (dx - pxv));
-    venc_bs_se(bs, 4 * (dy - pyv));
+    venc_bs_se(bs, (dx - pxv) << (g.subpel ? 0 : 2)); /* mvd_l0 in quarter samples */
+    venc_bs_se(bs, (dy - pyv) << (g.subpel ? 0 : 2));
     venc_bs_ue(bs, venc_cbp_inter_code[cbp]);
     if (cbp) venc_bs_se(bs, 0);
 }
