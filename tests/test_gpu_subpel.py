@@ -59,6 +59,31 @@ def test_refined_p_pictures_match_oracle_stage_by_stage(venc, orc, w, h, qp, sli
     eng.close()
 
 
+def test_half_sample_planes_match_the_numpy_restatement(venc, orc):
+    """k_hpel's b, h, j planes of a whole reference picture against tests/test_oracle_subpel.py's numpy planes (clamped taps at
+    every border), at a width that leaves the last 256-sample strip partly empty"""
+    from test_oracle_subpel import _numpy_planes
+    w, h = 304, 208
+    enc = orc.Encoder(w, h, qp=28, n_slices=2, keyint=30, threads=8, subpel=1)
+    eng = venc.Engine(w, h, qp=28, n_slices=2, max_items=1, in_slots=2, out_slots=2, subpel=1)
+    for t in range(2):
+        y, u, v = venc.synth_frame(w, h, t, 3)
+        if t == 1:
+            ref = enc.recon()[0]  # the I picture's reconstruction = the P step's reference
+        enc.encode(y, u, v)
+        eng.upload(t % 2, y, u, v)
+        eng.encode_step([t % 2], [t % 2], t == 0, t & 15, [0])
+        eng.sync()
+    got = eng.debug(15)
+    _, b, hh, j = _numpy_planes(ref)
+    H, W = ref.shape
+    for k, (name, want) in enumerate((("b", b), ("h", hh), ("j", j))):
+        want = want[4:4 + H, 4:4 + W]
+        bad = np.argwhere(got[k] != want)
+        assert len(bad) == 0, "%s plane: first mismatch at (y, x) = %s: %d vs %d (%d differ)" % (name, bad[0], got[k][tuple(bad[0])], want[tuple(bad[0])], len(bad))
+    eng.close()
+
+
 def test_refinement_with_gop_batches_rate_control_and_intra_modes(venc, orc):
     """everything the C API's presets switch on at once, through x264_encoder_encode: CRF, Intra16x16 V / H / DC, quarter-sample
     vectors, three GOPs per step"""

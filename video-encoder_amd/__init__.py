@@ -446,7 +446,7 @@ class Engine:
                   6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32),
                   8: ((ch + 25, (cw + 32) & ~15), np.uint32), 9: ((self.nmb,), np.uint8), 10: ((self.nmb,), np.uint8),
                   11: ((8,), np.uint64), 12: ((self.nmb, 32), np.int32), 13: ((self.nmb, 128), np.int32),
-                  14: ((self.nmb,), np.uint32)}
+                  14: ((self.nmb,), np.uint32), 15: ((3, ch, cw), np.uint8)}
         shape, dt = shapes[what]
         a = np.empty(shape, dt)
         self._ok(self.L.venc_debug_read(self.h, what, item, a.ctypes.data, a.nbytes), "venc_debug_read")

@@ -172,9 +172,9 @@ struct venc_ctx {
     int prof_n, prof_cap, prof_open;
 };
 
-enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_SUBPEL, KID_COUNT };
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_SUBPEL, KID_HPEL, KID_COUNT };
 /* "k_inter" = k_inter_fused (luma + chroma transforms) */
-static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma", "k_subpel"};
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma", "k_subpel", "k_hpel"};
 
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
     c->prof_open = 0;
@@ -279,6 +279,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
     (void)hipFree(c->b.pred_luma);
+    (void)hipFree(c->b.hpel);
     (void)hipFree(c->b.mvq);
     (void)hipFree(c->b.stamps);
     (void)hipFree(c->b.fix_count);
@@ -586,6 +587,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
     if (g.subpel) {
         OPEN_OK(hipMalloc(&b.pred_luma, G * nmb * 256));
+        OPEN_OK(hipMalloc(&b.hpel, G * 3 * (size_t)g.cw * g.ch + 64)); /* (+64: k_subpel's aligned row pieces end up to 6 bytes past a row) */
         OPEN_OK(hipMalloc(&b.mvq, (size_t)VENC_RING * G * nmb * 4));
         OPEN_OK(hipMemset(b.mvq, 0, (size_t)VENC_RING * G * nmb * 4));
     }
@@ -914,8 +916,11 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
 #endif
         if (!fuse) {
             if (g.subpel) { /* vectors -> quarter samples, predictions -> B.pred_luma (venc_subpel.hip) */
+                prof_begin(c, KID_HPEL, s1);
+                hipLaunchKernelGGL(k_hpel, dim3((g.cw / 4 + 63) / 64, (g.ch / HP_ROWS + 3) / 4, n_items), dim3(256), 0, s1, g, b, S);
+                prof_end(c, s1);
                 prof_begin(c, KID_SUBPEL, s1);
-                hipLaunchKernelGGL(k_subpel, dim3((band_mbs + 3) / 4, 1, n_items), dim3(256), 0, s1, g, b, S);
+                hipLaunchKernelGGL(k_subpel, dim3((band_mbs + 4 * SP_K - 1) / (4 * SP_K), 1, n_items), dim3(256), 0, s1, g, b, S);
                 prof_end(c, s1);
             }
             /* luma transform and chroma transform: independent blocks of one launch */
@@ -1315,6 +1320,13 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
                 return -1;
             }
             src = c->b.mvq + (lp_off + item) * nmb, n = nmb * 4;
+            break;
+        case 15: /* the half-sample planes b, h, j of the last P step's reference picture */
+            if (!c->b.hpel) {
+                SET_ERR("venc_debug_read: no half-sample planes (subpel = 0)");
+                return -1;
+            }
+            src = c->b.hpel + (size_t)item * 3 * g.cw * g.ch, n = (size_t)3 * g.cw * g.ch;
             break;
         case 1: src = c->b.levels + (lp_off + item) * nmb * VENC_MB_COEFS, n = nmb * VENC_MB_COEFS * 2; break;
         case 2: src = c->b.mbinfo + (lp_off + item) * nmb, n = nmb * sizeof(venc_mbinfo); break;
