@@ -278,7 +278,6 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
-    (void)hipFree(c->b.pred_luma);
     (void)hipFree(c->b.hpel);
     (void)hipFree(c->b.mvq);
     (void)hipFree(c->b.stamps);
@@ -550,6 +549,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     c->me_fast = getenv("VENC_ME_FAST") ? atoi(getenv("VENC_ME_FAST")) : 1;
     c->me_xcd = getenv("VENC_ME_XCD") && atoi(getenv("VENC_ME_XCD")) != 0;
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
+    if (g.subpel && (c->me_mode != 0 || c->inter_legacy)) {
+        SET_ERR("venc_open: sub-sample refinement runs behind the shipped search and transform only (VENC_ME / VENC_INTER select test kernels)");
+        venc_close(c);
+        return -1;
+    }
     OPEN_OK(hipMalloc(&b.me_flag, G * nmb));
     OPEN_OK(hipMemset(b.me_flag, 0, G * nmb));
     if (cfg->rc_mode) {
@@ -586,7 +590,6 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
     if (g.subpel) {
-        OPEN_OK(hipMalloc(&b.pred_luma, G * nmb * 256));
         OPEN_OK(hipMalloc(&b.hpel, G * 3 * (size_t)g.cw * g.ch + 64)); /* (+64: k_subpel's aligned row pieces end up to 6 bytes past a row) */
         OPEN_OK(hipMalloc(&b.mvq, (size_t)VENC_RING * G * nmb * 4));
         OPEN_OK(hipMemset(b.mvq, 0, (size_t)VENC_RING * G * nmb * 4));
@@ -914,21 +917,22 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             prof_end(c, s1);
         } else
 #endif
-        if (!fuse) {
-            if (g.subpel) { /* vectors -> quarter samples, predictions -> B.pred_luma (venc_subpel.hip) */
-                prof_begin(c, KID_HPEL, s1);
-                hipLaunchKernelGGL(k_hpel, dim3((g.cw / 4 + 63) / 64, (g.ch / HP_ROWS + 3) / 4, n_items), dim3(256), 0, s1, g, b, S);
-                prof_end(c, s1);
-                prof_begin(c, KID_SUBPEL, s1);
-                hipLaunchKernelGGL(k_subpel, dim3((band_mbs + 4 * SP_K - 1) / (4 * SP_K), 1, n_items), dim3(256), 0, s1, g, b, S);
-                prof_end(c, s1);
-            }
+        if (g.subpel && c->me_mode == 0 && !c->inter_legacy) {
+            /* sub-sample refinement (venc_subpel.hip): the reference's half-sample planes, then per macroblock the two
+             * stages and the luma transform at the refined vector; vectors -> B.mvq in quarter samples.  The chroma
+             * transform follows with the entropy batch on the second stream, as in the fused path. */
+            prof_begin(c, KID_HPEL, s1);
+            hipLaunchKernelGGL(k_hpel, dim3((g.cw / 4 + 63) / 64, (g.ch / HP_ROWS + 3) / 4, n_items), dim3(256), 0, s1, g, b, S);
+            prof_end(c, s1);
+            prof_begin(c, KID_SUBPEL, s1);
+            hipLaunchKernelGGL(k_subpel, dim3((band_mbs + 4 * SP_K - 1) / (4 * SP_K), 1, n_items), dim3(256), 0, s1, g, b, S);
+            prof_end(c, s1);
+            chroma_deferred = true;
+        } else if (!fuse) {
             /* luma transform and chroma transform: independent blocks of one launch */
             const int n_luma = (band_mbs + 15) / 16, n_chroma = (band_mbs + 31) / 32;
-            venc_bufs bt = b;
-            if (g.subpel) bt.mvsad = b.mvq; /* the refined vectors */
             prof_begin(c, KID_INTER, s1);
-            hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, bt, S, n_luma);
+            hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, b, S, n_luma);
             prof_end(c, s1);
         } else {
             /* The main chain ends here: search + luma transform, the flagged macroblocks' redo.  The next step's search
@@ -1015,7 +1019,7 @@ static int entropy_flush(venc_ctx *c) {
         for (int k = 0; k < n_steps; k++) {
             venc_bufs bk = c->b;
             const int rsk = rs0 + k;
-            bk.mvsad = c->b.mvsad + (size_t)rsk * GN;
+            bk.mvsad = (g.subpel ? c->b.mvq : c->b.mvsad) + (size_t)rsk * GN; /* (refined vectors: quarter samples) */
             bk.levels = c->b.levels + (size_t)rsk * GN * VENC_MB_COEFS;
             bk.mbinfo = c->b.mbinfo + (size_t)rsk * GN;
             if (c->cfg.rc_mode) bk.qp_cur = c->d_qp_ring + (size_t)((c->eb_first_step + k) % VENC_QP_RING) * c->b.max_items;

@@ -219,12 +219,7 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
     uint32_t cq[4], pq[4]; /* current and predicted rows, four samples per dword */
     load_cur4x4_pk(cur, cstride, pw, ph, px, py, (g.w & 3) == 0, cq);
     const int x0 = px + dx, y0 = py + dy;
-    if (g.subpel) {
-        /* the vector is fractional (quarter samples): k_subpel left the macroblock's prediction in B.pred_luma */
-        const uint32_t *pm = (const uint32_t *)(B.pred_luma + ((size_t)item * g.nmb + mb) * 256);
-#pragma unroll
-        for (int y = 0; y < 4; y++) pq[y] = pm[(blk_y(blk) * 4 + y) * 4 + blk_x(blk)];
-    } else if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) {
+    if (x0 >= 0 && x0 + 8 <= g.cw && y0 >= 0 && y0 + 4 <= g.ch) { /* (integer vectors only: under sub-sample refinement k_subpel transforms luma itself) */
         const uint32_t sh = (uint32_t)(x0 & 3);
         const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
 #pragma unroll

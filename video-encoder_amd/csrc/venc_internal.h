@@ -141,7 +141,6 @@ typedef struct {
     uint32_t *mvq;              /* sub-sample refinement: the step's vectors in QUARTER samples (SAD << 16 | qy << 8 | qx), what the
                                    transform and entropy kernels are handed as `mvsad`; the searches keep their integer vectors */
     uint8_t *hpel;              /* [item][3][cw * ch] sub-sample refinement: the half-sample planes b, h, j of the step's reference pictures (k_hpel) */
-    uint8_t *pred_luma;         /* [item][mb][256] sub-sample refinement: the luma prediction of every macroblock at its refined vector */
     const venc_qparams *qtab;   /* [52] quantiser constants of every QP (built by the host at open) */
     uint8_t *out_hdr;           /* device view of the pinned header pool: per slot venc_out_header + slice table */
     size_t out_hdr_stride;

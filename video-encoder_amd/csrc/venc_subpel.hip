@@ -110,7 +110,8 @@ __global__ __launch_bounds__(256) void k_hpel(venc_geom g, venc_bufs B, venc_ste
  * -1 .. 16 (h, j: -1 .. 15), byte column = integer column -1 .. 16 (b, j: -1 .. 15) + sh */
 struct sp_lds {
     uint32_t pl[4][SP_PD];               /* 0: integer samples G, 1: b, 2: h, 3: j */
-    uint32_t cur[64];                    /* the current macroblock: row y, dword x4 / 4 at [4 y + x4 / 4] */
+    uint32_t cur[SP_K][64];              /* the wave's current macroblocks: row y, dword x4 / 4 at [4 y + x4 / 4] */
+    uint32_t pred[SP_K][64];             /* their predictions at the refined vectors, same layout (the luma transform's input) */
     uint32_t win[SP_WR * SP_WS / 4];     /* border path only */
     int16_t b1[SP_WR * SP_B1S];          /* border path only */
 };
@@ -151,7 +152,7 @@ DEVFN uint32_t sp_pred4(const sp_lds &L, int sh, int qx, int qy, int y, int x4) 
  * over the groups comes back through a row mirror and four lane reads.  Returns the stage's best key below `best`
  * (else `best`).  QUARTER = false: positions on the doubled grid only (A alone). */
 template <bool QUARTER>
-DEVFN uint32_t sp_stage(const sp_lds &L, int sh, int cx, int cy, int step, int lane, uint32_t best) {
+DEVFN uint32_t sp_stage(const sp_lds &L, const uint32_t *curk, int sh, int cx, int cy, int step, int lane, uint32_t best) {
     const int c = lane >> 3, s2 = (lane & 7) * 2;
     const int kk = c < 4 ? c : c + 1; /* raster index of the neighbour in the 3 x 3 stencil, centre skipped */
     const int ey = kk / 3 - 1, ex = kk - (kk / 3) * 3 - 1;
@@ -178,7 +179,7 @@ DEVFN uint32_t sp_stage(const sp_lds &L, int sh, int cx, int cy, int step, int l
                 const uint32_t pb = __builtin_amdgcn_alignbyte(db[1], db[0], (uint32_t)(ob & 3));
                 pr = (pr | pb) - (((pr ^ pb) >> 1) & 0x7f7f7f7fu);
             }
-            sad = __builtin_amdgcn_sad_u8(pr, L.cur[(s2 + rr) * 4 + xq], sad);
+            sad = __builtin_amdgcn_sad_u8(pr, curk[(s2 + rr) * 4 + xq], sad);
         }
     sad += dpp_fetch<0xB1, 0xf>(sad, 0u);  /* quad_perm [1, 0, 3, 2] */
     sad += dpp_fetch<0x4E, 0xf>(sad, 0u);  /* quad_perm [2, 3, 0, 1] */
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void k_subpel(venc_geom g, venc_bufs B, venc_s
                 cur4 = (uint32_t)row[min(px, pw - 1)] | ((uint32_t)row[min(px + 1, pw - 1)] << 8) | ((uint32_t)row[min(px + 2, pw - 1)] << 16) |
                        ((uint32_t)row[min(px + 3, pw - 1)] << 24);
             }
-            L.cur[lane] = cur4;
+            L.cur[kmb][lane] = cur4;
         }
         int sh = 0;
         if (x0 >= 1 && x0 + 17 <= g.cw && y0 >= 1 && y0 + 17 <= g.ch) {
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void k_subpel(venc_geom g, venc_bufs B, venc_s
         uint32_t csad = m >> 16;
         for (int stage = 0; stage < g.subpel && stage < 2; stage++) {
             const int step = stage == 0 ? 2 : 1;
-            const uint32_t best = stage == 0 ? sp_stage<false>(L, sh, cx, cy, step, lane, csad << 4) : sp_stage<true>(L, sh, cx, cy, step, lane, csad << 4);
+            const uint32_t best = stage == 0 ? sp_stage<false>(L, L.cur[kmb], sh, cx, cy, step, lane, csad << 4) : sp_stage<true>(L, L.cur[kmb], sh, cx, cy, step, lane, csad << 4);
             const int idx = (int)(best & 15u); /* 0: the centre stays */
             if (idx) {
                 const int kk = idx <= 4 ? idx - 1 : idx;
@@ -310,8 +311,26 @@ __global__ __launch_bounds__(256) void k_subpel(venc_geom g, venc_bufs B, venc_s
             csad = best >> 4;
         }
         if (lane == 0) B.mvq[(size_t)item * g.nmb + mb] = (csad << 16) | (((uint32_t)(4 * dy + cy) & 255u) << 8) | ((uint32_t)(4 * dx + cx) & 255u);
-        ((uint32_t *)(B.pred_luma + ((size_t)item * g.nmb + mb) * 256))[lane] = sp_pred4(L, sh, cx, cy, y, x4);
+        L.pred[kmb][lane] = sp_pred4(L, sh, cx, cy, y, x4);
         __builtin_amdgcn_s_waitcnt(0xc07f); /* the pieces are rebuilt for the wave's next macroblock */
         __builtin_amdgcn_wave_barrier();
+    }
+    /* the luma transform of the wave's SP_K macroblocks, all at once: 16 lanes per macroblock, one 4x4 block each, current
+     * and predicted rows from the wave's LDS copies (luma_block_code, venc_inter2.hip: residual ... reconstruction, levels) */
+    static_assert(SP_K == 4, "four macroblocks x sixteen blocks = the lanes of a wave");
+    {
+        const int mbk = lane >> 4, blk = lane & 15;
+        const int mb_raw = S.mb0 + ((int)blockIdx.x * 4 + wave) * SP_K + mbk;
+        const bool valid = mb_raw < S.mb1;
+        const int mb = valid ? mb_raw : S.mb1 - 1;
+        venc_qparams ql, qc;
+        step_qparams(g, B, S, item, ql, qc);
+        uint32_t cq[4], pq[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            cq[r] = L.cur[mbk][(blk_y(blk) * 4 + r) * 4 + blk_x(blk)];
+            pq[r] = L.pred[mbk][(blk_y(blk) * 4 + r) * 4 + blk_x(blk)];
+        }
+        luma_block_code(g, B, S, item, lane, mb, valid, cq, pq, ql);
     }
 }
