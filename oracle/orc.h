@@ -54,6 +54,7 @@ typedef struct {
                             GOP-sharded run reproduce the single-encoder stream */
     int rc_mode;         /* 0: fixed QP; 1: picture QP by spec/CODEC.md section 1a (qp = the base QP) */
     int intra_modes;     /* 0: Intra16x16 DC prediction only; 1: vertical / horizontal / DC chosen by SAD (spec/CODEC.md section 3) */
+    int deblock;         /* 0: disable_deblocking_filter_idc = 1; 1: in-loop filter inside every slice (idc 2; spec/CODEC.md section 5a) */
     int subpel;          /* 0: integer-sample vectors; 1: half-sample refinement; 2: half then quarter (spec/CODEC.md section 2a) */
 } orc_params;
 
@@ -91,6 +92,7 @@ const uint16_t *orc_enc_sad(const orc_enc *e);     /* [mb] best SAD (P frames) *
 const int16_t *orc_enc_levels(const orc_enc *e);   /* [mb][27][16] */
 const uint32_t *orc_enc_mb_bits(const orc_enc *e); /* [mb] bits of macroblock_layer (+skip_run) */
 const uint8_t *orc_enc_recon(const orc_enc *e, int plane, int *stride); /* coded size */
+const uint8_t *orc_enc_recon_unfiltered(const orc_enc *e, int plane);  /* the same before the in-loop filter (deblock = 1), tight planes */
 /* first MB row of every slice, n_slices+1 entries */
 const int *orc_enc_slice_rows(const orc_enc *e);
 

@@ -16,6 +16,7 @@
  */
 #include "orc.h"
 #include "orc_interp.h"
+#include "orc_deblock.h"
 #include "orc_tables.h"
 
 #include <stdio.h>
@@ -71,6 +72,7 @@ struct orc_dec {
     int8_t *mv;
     uint8_t *nnz_l, *nnz_cb, *nnz_cr;
     int *mb_slice; /* slice id of every MB of the current picture, -1 = not decoded */
+    uint8_t *mb_intra, *mb_qp, *mb_dbk; /* per MB: intra, QP_Y, in-loop filter on (disable_deblocking_filter_idc == 2) */
     int n_slices_seen;
     uint8_t *rbsp;
     size_t rbsp_cap;
@@ -89,6 +91,9 @@ void orc_dec_close(orc_dec *d) {
     free(d->nnz_cb);
     free(d->nnz_cr);
     free(d->mb_slice);
+    free(d->mb_intra);
+    free(d->mb_qp);
+    free(d->mb_dbk);
     free(d->rbsp);
     free(d);
 }
@@ -143,12 +148,18 @@ static int parse_sps(orc_dec *d, br_t *b) {
         free(d->nnz_cb);
         free(d->nnz_cr);
         free(d->mb_slice);
+        free(d->mb_intra);
+        free(d->mb_qp);
+        free(d->mb_dbk);
         size_t nmb = (size_t)mbw * mbh;
         d->mv = (int8_t *)calloc(nmb * 2, 1);
         d->nnz_l = (uint8_t *)calloc(nmb * 16, 1);
         d->nnz_cb = (uint8_t *)calloc(nmb * 4, 1);
         d->nnz_cr = (uint8_t *)calloc(nmb * 4, 1);
         d->mb_slice = (int *)calloc(nmb, sizeof(int));
+        d->mb_intra = (uint8_t *)calloc(nmb, 1);
+        d->mb_qp = (uint8_t *)calloc(nmb, 1);
+        d->mb_dbk = (uint8_t *)calloc(nmb, 1);
     }
     d->mbw = mbw;
     d->mbh = mbh;
@@ -392,11 +403,16 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             FAIL(d, "MMCO unsupported");
     }
     int qp = d->pic_init_qp + br_se(b);
+    int dbk = 0; /* in-loop filter of this slice's macroblocks (8.7, orc_deblock.h): off (idc 1) or within the slice (idc 2) */
     if (d->deblock_ctrl) {
         int idc = (int)br_ue(b);
-        if (idc != 1) FAIL(d, "deblocking enabled: unsupported");
+        if (idc != 1 && idc != 2) FAIL(d, "disable_deblocking_filter_idc %d unsupported (filtering across slice boundaries)", idc);
+        if (idc == 2) {
+            if (br_se(b) != 0 || br_se(b) != 0) FAIL(d, "deblocking filter offsets unsupported");
+            dbk = 1;
+        }
     } else
-        FAIL(d, "deblocking enabled: unsupported");
+        FAIL(d, "deblocking without filter control: unsupported (would filter across slice boundaries)");
     if (b->err) FAIL(d, "slice header truncated");
 
     /* end of slice data: position of the rbsp_stop_one_bit */
@@ -443,6 +459,7 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
         int mx = mb % d->mbw, my = mb / d->mbw;
         int t = skip ? 0 : (int)br_ue(b);
         d->mb_slice[mb] = sid;
+        d->mb_dbk[mb] = (uint8_t)dbk;
         int aL = mb_avail(d, mx - 1, my, sid), aT = mb_avail(d, mx, my - 1, sid);
         if (st == 2 || t >= 5) {
             if (st == 0) FAIL(d, "intra MB in P slice unsupported");
@@ -602,6 +619,8 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             if (decode_chroma(d, b, mx, my, sid, cbp >> 4, qp, pred) < 0) return -1;
         }
         if (b->err) FAIL(d, "bitstream error in mb %d", mb);
+        d->mb_intra[mb] = (uint8_t)(st == 2 || t >= 5);
+        d->mb_qp[mb] = (uint8_t)qp;
         mb++;
     }
     if (b->pos != end) FAIL(d, "slice data overran the stop bit (pos %zu end %zu)", b->pos, end);
@@ -649,8 +668,14 @@ int orc_dec_decode(orc_dec *d, const uint8_t *data, size_t size) {
         o += n;
     }
     if (o != size) FAIL(d, "trailing bytes");
-    if (got_pic)
+    if (got_pic) {
         for (int i = 0; i < d->mbw * d->mbh; i++)
             if (d->mb_slice[i] < 0) FAIL(d, "macroblock %d not covered by any slice", i);
+        /* the picture is complete: in-loop filter (8.7) of the slices that ask for it; the filtered picture is what is
+         * output and what the next picture predicts from */
+        const orc_dbk k = {{d->cur[0], d->cur[1], d->cur[2]}, {d->cw, d->cw / 2, d->cw / 2}, d->mbw, d->mbh, d->mb_intra, d->nnz_l, d->mv,
+                           d->mb_slice, d->mb_qp, d->mb_dbk, orc_chroma_qp};
+        orc_deblock_picture(&k);
+    }
     return got_pic;
 }

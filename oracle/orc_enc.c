@@ -13,6 +13,7 @@
  */
 #include "orc.h"
 #include "orc_interp.h"
+#include "orc_deblock.h"
 #include "orc_tables.h"
 
 #include <stdlib.h>
@@ -314,6 +315,7 @@ struct orc_enc {
     orc_params p;
     int mbw, mbh, cw, ch;
     uint8_t *cur[3], *rec[3];
+    uint8_t *rec_pre[3]; /* deblock: the reconstruction before the in-loop filter (introspection) */
     uint8_t *refp[3]; /* padded reference planes (edge-replicated, 8.4.2.2.1 clipping) */
     int refp_stride[3];
     long frame_idx;
@@ -423,6 +425,7 @@ void orc_enc_close(orc_enc *e) {
         free(e->cur[k]);
         free(e->rec[k]);
         free(e->refp[k]);
+        free(e->rec_pre[k]);
     }
     for (int s = 0; s < e->p.n_slices; s++) free(e->slice_buf[s]);
     free(e->slice_buf);
@@ -452,6 +455,7 @@ const uint16_t *orc_enc_sad(const orc_enc *e) { return e->sad; }
 const int16_t *orc_enc_levels(const orc_enc *e) { return e->levels; }
 const uint32_t *orc_enc_mb_bits(const orc_enc *e) { return e->mb_bits; }
 const int *orc_enc_slice_rows(const orc_enc *e) { return e->slice_rows; }
+const uint8_t *orc_enc_recon_unfiltered(const orc_enc *e, int plane) { return e->rec_pre[plane] ? e->rec_pre[plane] : e->rec[plane]; }
 const uint8_t *orc_enc_recon(const orc_enc *e, int plane, int *stride) {
     if (stride) *stride = plane ? e->cw / 2 : e->cw;
     return e->rec[plane];
@@ -1057,7 +1061,12 @@ static void write_slice_header(const orc_enc *e, bw_t *b, int first_mb, int idr)
     } else
         bw_put(b, 0, 1); /* adaptive_ref_pic_marking_mode */
     bw_se(b, e->qp_cur - e->p.qp); /* slice_qp_delta: 0 at fixed QP */
-    bw_ue(b, 1);         /* disable_deblocking_filter_idc */
+    if (e->p.deblock) {
+        bw_ue(b, 2); /* disable_deblocking_filter_idc: filter, but not across slice boundaries (spec/CODEC.md section 5a) */
+        bw_se(b, 0); /* slice_alpha_c0_offset_div2 */
+        bw_se(b, 0); /* slice_beta_offset_div2 */
+    } else
+        bw_ue(b, 1); /* disable_deblocking_filter_idc */
 }
 
 int orc_enc_set_band(orc_enc *e, int slice_first, int slice_count) {
@@ -1173,6 +1182,27 @@ long orc_enc_encode(orc_enc *e, const uint8_t *y, int sy, const uint8_t *u, int 
     *nal_count = n;
     *is_idr = idr;
 
+    if (e->p.deblock)
+        for (int k = 0; k < 3; k++) {
+            size_t n = (size_t)e->cw * e->ch / (k ? 4 : 1);
+            if (!e->rec_pre[k]) e->rec_pre[k] = (uint8_t *)malloc(n);
+            memcpy(e->rec_pre[k], e->rec[k], n);
+        }
+    if (e->p.deblock) { /* in-loop filter of the coded slices (8.7, orc_deblock.h): the picture a decoder outputs and predicts from */
+        int nmb = e->mbw * e->mbh;
+        uint8_t *intra = (uint8_t *)malloc((size_t)nmb * 3);
+        int32_t *slice = (int32_t *)malloc((size_t)nmb * sizeof(int32_t));
+        uint8_t *qp = intra + nmb, *en = intra + 2 * nmb;
+        memset(intra, idr ? 1 : 0, (size_t)nmb);
+        memset(qp, e->qp_cur, (size_t)nmb);
+        memset(en, 0, (size_t)nmb);
+        for (int s = 0; s < e->p.n_slices; s++)
+            for (int mb = e->slice_rows[s] * e->mbw; mb < e->slice_rows[s + 1] * e->mbw; mb++) slice[mb] = s, en[mb] = (uint8_t)(s >= e->band_s0 && s < e->band_s1);
+        const orc_dbk k = {{e->rec[0], e->rec[1], e->rec[2]}, {e->cw, e->cw / 2, e->cw / 2}, e->mbw, e->mbh, intra, e->nnz_l, e->mvq, slice, qp, en, orc_chroma_qp};
+        orc_deblock_picture(&k);
+        free(intra);
+        free(slice);
+    }
     /* reconstructed frame becomes the (edge-replicated) reference of the next */
     pad_plane(e->refp[0], e->refp_stride[0], LPAD, e->rec[0], e->cw, e->ch);
     pad_plane(e->refp[1], e->refp_stride[1], CPAD, e->rec[1], e->cw / 2, e->ch / 2);

@@ -18,7 +18,7 @@ MAX_NALS = 512
 
 class OrcParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "keyint", "fps_num", "fps_den",
-                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode", "intra_modes", "subpel")]
+                                       "sar_w", "sar_h", "threads", "idr_base", "rc_mode", "intra_modes", "deblock", "subpel")]
 
 
 class OrcNal(C.Structure):
@@ -26,7 +26,7 @@ class OrcNal(C.Structure):
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, f) for f in ("orc_enc.c", "orc_dec.c", "orc.h", "orc_interp.h", "orc_tables.h", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_enc.c", "orc_dec.c", "orc.h", "orc_interp.h", "orc_deblock.h", "orc_tables.h", "Makefile")]
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB
@@ -91,12 +91,12 @@ class Frame:
 
 
 class Encoder:
-    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False, intra_modes=False, subpel=0):
+    def __init__(self, width, height, qp=26, n_slices=1, keyint=30, fps=(30, 1), sar=(0, 0), threads=1, idr_base=0, rc=False, intra_modes=False, subpel=0, deblock=False):
         """rc: picture QP by spec/CODEC.md section 1a (the CRF approximation), qp = its base; else fixed QP.
         intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only.
         subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a)."""
         self.L = lib()
-        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(bool(intra_modes)), int(subpel))
+        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(bool(intra_modes)), int(bool(deblock)), int(subpel))
         self.h = self.L.orc_enc_open(C.byref(self.params))
         if not self.h:
             raise ValueError("orc_enc_open rejected the parameters")
@@ -166,6 +166,13 @@ class Encoder:
     def slice_rows(self):
         n = min(max(1, self.params.n_slices), self.mbh)
         return np.ctypeslib.as_array(self.L.orc_enc_slice_rows(self.h), (n + 1,)).copy()
+
+    def recon_unfiltered(self):
+        """the last picture's reconstruction before the in-loop filter (= recon() without deblocking)"""
+        self.L.orc_enc_recon_unfiltered.restype = C.POINTER(C.c_uint8)
+        self.L.orc_enc_recon_unfiltered.argtypes = [C.c_void_p, C.c_int]
+        cw, ch = self.mbw * 16, self.mbh * 16
+        return [np.ctypeslib.as_array(self.L.orc_enc_recon_unfiltered(self.h, p), (ch // (2 if p else 1), cw // (2 if p else 1))).copy() for p in range(3)]
 
     def recon(self):
         out = []
