@@ -51,6 +51,8 @@ typedef struct {
     int intra_modes;   /* 0: Intra16x16 with DC prediction only (the three-kernel I path); 1: vertical / horizontal / DC chosen
                           per macroblock by SAD (spec/CODEC.md section 3; one wavefront kernel, ~3x the I-step time, hidden
                           behind the previous unit's P steps) */
+    int deblock;       /* 0: no in-loop filter (disable_deblocking_filter_idc = 1); 1: H.264 8.7 inside every slice (idc 2,
+                          spec/CODEC.md section 5a): a slice-wise wavefront kernel after every picture's reconstruction */
     int subpel;        /* 0: integer-sample motion vectors (the search + transform run fused); 1: half-sample refinement; 2: half-
                           then quarter-sample (spec/CODEC.md section 2a: H.264 8.4.2.2.1 interpolation, exhaustive 8-neighbour
                           stages; P steps then run search, refinement and transform as separate kernels).  Whole-picture

@@ -114,6 +114,10 @@ typedef struct x264_param_t {
          * quarter-sample stage (x264_param_default_preset's default for every preset but "ultrafast", as in libx264).
          * Slice-band encoders run with 0. */
         int i_subpel;
+        /* in-loop deblocking filter (libx264's b_deblocking_filter, on in its defaults and in every preset): 1 = H.264 8.7
+         * inside every slice (disable_deblocking_filter_idc = 2: slices, and with them GPU bands, stay independent;
+         * x264_param_default_preset's default), 0 = off (what bench.py measures) */
+        int i_deblock;
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;

@@ -434,7 +434,7 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
     # the C driver opens the encoder as the reference does: X264_RC_CRF (av_encode.c:400-401) = spec/CODEC.md section 1a
     # ... and with the preset's intra modes (x264_param_default_preset: Intra16x16 V / H / DC)
     # ... and its sub-sample refinement (every preset but ultrafast: half- then quarter-sample stage)
-    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True, subpel=2)
+    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True, subpel=2, deblock=True)
     dec = orc.Decoder()
     got = samples_of(data, t)
     for k, f in enumerate(frames):
@@ -584,7 +584,7 @@ def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path)
     assert pct == sorted(pct) and pct[-1] <= 100.0 and pct[-1] > 50.0
     t = read_track(open(mp4, "rb").read())
     assert len(t["stsz"]) == 9 and t["stss"] == [1, 6] and t["timescale"] == 25
-    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True, subpel=2)
+    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True, subpel=2, deblock=True)
     got = samples_of(open(mp4, "rb").read(), t)
     for k in range(9):
         ref = enc.encode(*frames[k])

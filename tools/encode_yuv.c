@@ -89,6 +89,7 @@ static bool enc_x264_open(int width, int height, int fps_num, int fps_den, int s
      * ultrafast 0), VENC_INTRA_MODES=0/1 (Intra16x16 V / H / DC; preset default 1) */
     if (getenv("VENC_SUBPEL")) params.hip.i_subpel = atoi(getenv("VENC_SUBPEL"));
     if (getenv("VENC_INTRA_MODES")) params.hip.i_intra_modes = atoi(getenv("VENC_INTRA_MODES"));
+    if (getenv("VENC_DEBLOCK")) params.hip.i_deblock = atoi(getenv("VENC_DEBLOCK"));
     if (x264_param_apply_profile(&params, profile) != 0) {
         fprintf(stderr, "x264: failed to apply profile %s\n", profile);
         return false;

@@ -48,7 +48,7 @@ def build(verbose=False):
 # ----------------------------------------------------------------------------- C-ABI structs
 class VencConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("width", "height", "qp", "n_slices", "max_items", "in_slots", "out_slots",
-                                       "device", "rc_mode", "intra_modes", "subpel")]
+                                       "device", "rc_mode", "intra_modes", "deblock", "subpel")]
 
 
 class VencSlice(C.Structure):
@@ -80,7 +80,7 @@ class _Hip(C.Structure):
     _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int),
                 ("i_slice_first", C.c_int), ("i_slice_count", C.c_int), ("pf_exchange", EXCHANGE_FN),
                 ("p_exchange_user", C.c_void_p), ("i_rccl_world", C.c_int), ("i_rccl_rank", C.c_int),
-                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128), ("i_intra_modes", C.c_int), ("i_subpel", C.c_int)]
+                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128), ("i_intra_modes", C.c_int), ("i_subpel", C.c_int), ("i_deblock", C.c_int)]
 
 
 class X264Param(C.Structure):
@@ -334,13 +334,14 @@ def synth_frame(width, height, frame_index, seed=0x1234ABCD):
 class Engine:
     """One encoder context on one GPU: frame slots in, slice RBSPs out."""
 
-    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None, rc=False, intra_modes=False, subpel=0):
+    def __init__(self, width, height, qp=26, n_slices=8, max_items=1, in_slots=4, out_slots=4, device=0, lib=None, rc=False, intra_modes=False, subpel=0, deblock=False):
         """lib: a library bound with bind_hip() instead of the product library (tests load the legacy build this way).
         rc: picture QP by spec/CODEC.md section 1a (qp = the base) instead of fixed QP.
         intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only.
-        subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a)."""
+        subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a).
+        deblock: in-loop deblocking filter inside every slice (spec/CODEC.md section 5a)."""
         self.L = lib if lib is not None else hip_lib()
-        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)), int(bool(intra_modes)), int(subpel))
+        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)), int(bool(intra_modes)), int(bool(deblock)), int(subpel))
         h = C.c_void_p()
         rc = self.L.venc_open(C.byref(self.cfg), C.byref(h))
         if rc != 0:
@@ -477,7 +478,7 @@ class X264Encoder:
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
                  tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0,
-                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0):
+                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0, deblock=False):
         """slice_first / slice_count / exchange: slice-parallel multi-GPU mode (include/x264.h, hip extension);
         exchange(engine_view, n_items) is called after every picture that a P picture follows.
         rccl = (world, rank, id_bytes, halo_rows): the engine does the exchange itself in C over RCCL
@@ -502,6 +503,7 @@ class X264Encoder:
         # definition that bench.py and the golden fixtures are frozen on
         p.hip.i_intra_modes = int(bool(intra_modes))
         p.hip.i_subpel = int(subpel)  # (likewise: the C API's presets refine to quarter samples)
+        p.hip.i_deblock = int(bool(deblock))  # (and filter in the loop)
         if rccl is not None:
             world, rank, ident, halo = rccl
             p.hip.i_rccl_world, p.hip.i_rccl_rank, p.hip.i_halo_rows = world, rank, halo

@@ -25,6 +25,7 @@
 #endif
 #include "venc_me3.hip"
 #include "venc_subpel.hip"
+#include "venc_deblock.hip"
 #include "venc_cavlc_p.hip"
 #include "venc_intra2.hip"
 #include "venc_synth.h"
@@ -172,9 +173,9 @@ struct venc_ctx {
     int prof_n, prof_cap, prof_open;
 };
 
-enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_SUBPEL, KID_HPEL, KID_COUNT };
+enum { KID_ME = 0, KID_INTER, KID_INTRA, KID_CAVLC, KID_SCAN, KID_PACK, KID_REFSUM, KID_MEFIX, KID_INTER_C, KID_SUBPEL, KID_HPEL, KID_DEBLOCK, KID_COUNT };
 /* "k_inter" = k_inter_fused (luma + chroma transforms) */
-static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma", "k_subpel", "k_hpel"};
+static const char *const k_kernel_names[KID_COUNT] = {"k_me", "k_inter", "k_intra", "k_cavlc", "k_scan", "k_pack", "k_refsum", "k_me_fix", "k_inter_chroma", "k_subpel", "k_hpel", "k_deblock"};
 
 static void prof_begin(venc_ctx *c, int kid, hipStream_t st) {
     c->prof_open = 0;
@@ -210,6 +211,15 @@ static void fill_qparams(venc_qparams *q, int qp) {
 }
 
 static int entropy_flush(venc_ctx *c);
+/* the in-loop filter of a step's pictures (venc_deblock.hip): one block per (slice, item), a wave per macroblock row */
+static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, const venc_bufs &b, const venc_step &S, int n_items, int planes) {
+    int max_rows = 1;
+    for (int s = S.slice0; s < S.slice1; s++) max_rows = c->slice_rows[s + 1] - c->slice_rows[s] > max_rows ? c->slice_rows[s + 1] - c->slice_rows[s] : max_rows;
+    const int waves = max_rows < DBK_MAX_WAVES ? max_rows : DBK_MAX_WAVES;
+    prof_begin(c, KID_DEBLOCK, st);
+    hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), 0, st, g, b, S, planes);
+    prof_end(c, st);
+}
 /* the chroma transform of the last P step runs on the second stream: anything on the main stream that touches chroma
  * reconstructions (intra pictures, band export / import) waits for it */
 static hipError_t main_waits_for_chroma(venc_ctx *c) {
@@ -549,6 +559,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     c->me_fast = getenv("VENC_ME_FAST") ? atoi(getenv("VENC_ME_FAST")) : 1;
     c->me_xcd = getenv("VENC_ME_XCD") && atoi(getenv("VENC_ME_XCD")) != 0;
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
+    if (cfg->deblock && (c->me_mode != 0 || c->inter_legacy || (getenv("VENC_INTRA") && !strcmp(getenv("VENC_INTRA"), "legacy")))) {
+        SET_ERR("venc_open: the in-loop filter runs behind the shipped kernels only (VENC_ME / VENC_INTER / VENC_INTRA select test kernels)");
+        venc_close(c);
+        return -1;
+    }
     if (g.subpel && (c->me_mode != 0 || c->inter_legacy)) {
         SET_ERR("venc_open: sub-sample refinement runs behind the shipped search and transform only (VENC_ME / VENC_INTER select test kernels)");
         venc_close(c);
@@ -755,6 +770,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     S.qp_idr = c->g_idr.qp;
     S.rc_history = !is_idr && c->last_step_p;
     S.me_stop = c->me_stop;
+    S.deblock = c->cfg.deblock ? 1 : 0;
     S.me_fast = c->me_fast;
     S.slice0 = c->band_s0;
     S.slice1 = c->band_s1;
@@ -861,6 +877,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_intra_rec, dim3((band_mbs + 7) / 8, 1, n_items), dim3(256), 0, s1, gi, b, S);
         }
         prof_end(c, s1);
+        if (c->cfg.deblock) launch_deblock(c, s1, c->cfg.rc_mode ? c->g_idr : g, b, S, n_items, 3);
         if (intra_async) {
             HIP_OK(hipEventRecord(c->ev_intra, s1));
             c->intra_pending = 1;
@@ -928,18 +945,26 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             hipLaunchKernelGGL(k_subpel, dim3((band_mbs + 4 * SP_K - 1) / (4 * SP_K), 1, n_items), dim3(256), 0, s1, g, b, S);
             prof_end(c, s1);
             chroma_deferred = true;
+            if (c->cfg.deblock) { /* luma here, for the next search; chroma behind its transform on the second stream */
+                venc_bufs bt = b;
+                bt.mvsad = b.mvq;
+                launch_deblock(c, s1, g, bt, S, n_items, 1);
+            }
         } else if (!fuse) {
             /* luma transform and chroma transform: independent blocks of one launch */
             const int n_luma = (band_mbs + 15) / 16, n_chroma = (band_mbs + 31) / 32;
             prof_begin(c, KID_INTER, s1);
             hipLaunchKernelGGL(k_inter_fused, dim3(n_luma + n_chroma, 1, n_items), dim3(256), 0, s1, g, b, S, n_luma);
             prof_end(c, s1);
+            if (c->cfg.deblock) launch_deblock(c, s1, g, b, S, n_items, 3);
         } else {
             /* The main chain ends here: search + luma transform, the flagged macroblocks' redo.  The next step's search
              * needs nothing else (it reads luma only).  The chroma transforms of a batch of steps follow on the second
              * stream, one after the other (chroma reconstructions chain from step to step), ahead of the batch's entropy
              * chain and beside the next searches: ONE event hand-off per batch, none between the kernels of the main chain. */
             chroma_deferred = c->fuse_luma < 2;
+            /* in-loop filter: luma here (the next search reads it); chroma behind its transform on the second stream */
+            if (c->cfg.deblock) launch_deblock(c, s1, g, b, S, n_items, chroma_deferred ? 1 : 3);
         }
     }
 #ifdef VENC_LEGACY_KERNELS
@@ -1026,6 +1051,7 @@ static int entropy_flush(venc_ctx *c) {
             prof_begin(c, KID_INTER, s2);
             hipLaunchKernelGGL(k_inter_fused, dim3((band_mbs + 31) / 32, 1, c->eb_step[k].n_items), dim3(256), 0, s2, g, bk, c->eb_step[k], 0);
             prof_end(c, s2);
+            if (c->cfg.deblock) launch_deblock(c, s2, g, bk, c->eb_step[k], c->eb_step[k].n_items, 2); /* (the next step's chroma transform predicts from the filtered planes) */
         }
         if (c->overlap) {
             HIP_OK(hipEventRecord(c->ev_chroma, s2));

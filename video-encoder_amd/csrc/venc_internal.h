@@ -68,6 +68,7 @@ typedef struct {
 
 typedef struct {
     int n_items;
+    int deblock; /* the in-loop filter is on: slice headers say so (k_deblock does the filtering) */
     int is_idr;
     int frame_num;
     int parity; /* recon buffer written this step (index into the ring of VENC_RECON buffers) */

@@ -701,7 +701,12 @@ DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int i
     }
     /* slice_qp_delta: 0 at fixed QP; under rate control the picture's QP (spec/CODEC.md section 1a) against pic_init_qp */
     venc_bs_se(bs, S.rc_mode ? (S.is_idr ? S.qp_idr : B.qp_cur[item]) - S.qp_base : 0);
-    venc_bs_ue(bs, 1); /* disable_deblocking_filter_idc */
+    if (S.deblock) {
+        venc_bs_ue(bs, 2); /* disable_deblocking_filter_idc: the in-loop filter inside the slice (spec/CODEC.md section 5a) */
+        venc_bs_se(bs, 0); /* slice_alpha_c0_offset_div2 */
+        venc_bs_se(bs, 0); /* slice_beta_offset_div2 */
+    } else
+        venc_bs_ue(bs, 1); /* disable_deblocking_filter_idc */
 }
 
 /* 16x16 motion vector prediction (8.4.1.3.1) of macroblock mb from its neighbours A (left), B (top), C (top right, or D top

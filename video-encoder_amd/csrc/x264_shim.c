@@ -123,6 +123,7 @@ int x264_param_default_preset(x264_param_t *param, const char *preset, const cha
     param->hip.i_gop_batch = 1;
     param->hip.i_intra_modes = 1;
     param->hip.i_subpel = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 2;
+    param->hip.i_deblock = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 1; /* (libx264: ultrafast sets no-deblock) */
     if (preset) {
         if (!name_in(preset, k_presets)) return -1;
         snprintf(param->psz_preset, sizeof(param->psz_preset), "%s", preset);
@@ -205,6 +206,7 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     cfg.out_slots = h->pool;
     cfg.device = param->hip.i_device;
     cfg.intra_modes = param->hip.i_intra_modes != 0;
+    cfg.deblock = param->hip.i_deblock != 0;
     /* sub-sample refinement: whole-picture encoders only (the six-tap filter reaches three rows past a band's halo) */
     cfg.subpel = (param->hip.i_slice_count <= 0 && param->hip.i_slice_first <= 0 && param->hip.i_rccl_world <= 0) ? param->hip.i_subpel : 0;
     /* X264_RC_CRF (what the reference asks for, av_encode.c:400-401): the rate factor is the base QP and every picture's QP
