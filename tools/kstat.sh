@@ -11,3 +11,13 @@ f = glob.glob(sys.argv[1] + "/prof/*/*kernel_stats.csv")[0]
 for r in csv.DictReader(open(f)):
     print("%-60s calls %6s avg %10.1f us  total %8.2f ms  %5s%%" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 PY
+# KSTAT_KERNEL=name: the distribution of that kernel's durations (us) from the trace
+if [ -n "$KSTAT_KERNEL" ]; then python3 - $O $KSTAT_KERNEL <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + "/prof/*/*kernel_trace.csv")[0]
+d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(sys.argv[2]))
+n = len(d)
+print(sys.argv[2], "n", n, "min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % (d[0], d[n // 10], d[n // 2], d[9 * n // 10], d[-1]))
+print(" ".join("%.0f" % x for x in d[:: max(1, n // 40)]))
+PY
+fi
