@@ -15,6 +15,11 @@ names = {"bench_default": "bench_default_1080p_with_2160p_pcie_cpu_bitexact", "b
          "bench_1080p_serial": "bench_1080p_serial_steps",
          "bench_2160p_serial": "bench_2160p_serial_steps", "bench_slices1": "bench_2160p_slices_1rank",
          "bench_slices2": "bench_2160p_slices_2rank_gloo_rehearsal", "bench_streams2": "bench_1080p_streams_2rank_gloo_rehearsal"}
+for p in glob.glob(os.path.join(src, "bench_tool_*.json")):
+    names[os.path.basename(p)[:-5]] = os.path.basename(p)[:-5]
+ks = glob.glob(os.path.join(src, "stats_tools", "*", "*kernel_stats.csv"))
+if ks:
+    shutil.copy(ks[0], os.path.join(dst, "%s_kernel_stats_1080p_all_tools_isolated.csv" % tag))
 for a, b in names.items():
     p = os.path.join(src, a + ".json")
     if os.path.exists(p):
