@@ -18,29 +18,30 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("w,h,n_slices,cuts,halo_rows,items", [
-    (352, 288, 6, (0, 2, 6), 0, 1),        # two bands, whole-band exchange
-    (352, 288, 6, (0, 1, 3, 6), 16, 1),    # three bands (one of a single slice), halo exchange
-    (1920, 1088, 8, (0, 3, 8), 16, 2),     # full-HD geometry, odd first band row count, two items in lock-step
+@pytest.mark.parametrize("w,h,n_slices,cuts,halo_rows,items,deblock", [
+    (352, 288, 6, (0, 2, 6), 0, 1, False),        # two bands, whole-band exchange
+    (352, 288, 6, (0, 1, 3, 6), 16, 1, False),    # three bands (one of a single slice), halo exchange
+    (1920, 1088, 8, (0, 3, 8), 16, 2, False),     # full-HD geometry, odd first band row count, two items in lock-step
+    (352, 288, 6, (0, 1, 3, 6), 16, 1, True),     # in-loop filter inside slices (idc 2): bands stay independent, halos carry filtered rows
 ])
-def test_band_engines_reproduce_the_whole_picture_engine(venc, orc, w, h, n_slices, cuts, halo_rows, items):
+def test_band_engines_reproduce_the_whole_picture_engine(venc, orc, w, h, n_slices, cuts, halo_rows, items, deblock):
     """One engine per band on the same GPU, rows swapped with venc_band_export / venc_band_import through a
     device chunk: slices, motion vectors and (whole-band mode) every rank's full reconstruction equal the
     whole-picture engine's, which equals the oracle's."""
     import torch
     n, keyint, qp = 5, 4, 27
     clips = [[venc.synth_frame(w, h, t, 0x1234ABCD + 17 * i) for t in range(n)] for i in range(items)]
-    whole = venc.Engine(w, h, qp=qp, n_slices=n_slices, max_items=items, in_slots=2 * items, out_slots=2 * items)
+    whole = venc.Engine(w, h, qp=qp, n_slices=n_slices, max_items=items, in_slots=2 * items, out_slots=2 * items, deblock=deblock)
     bands = []
     for a, b in zip(cuts[:-1], cuts[1:]):
-        e = venc.Engine(w, h, qp=qp, n_slices=n_slices, max_items=items, in_slots=2 * items, out_slots=2 * items)
+        e = venc.Engine(w, h, qp=qp, n_slices=n_slices, max_items=items, in_slots=2 * items, out_slots=2 * items, deblock=deblock)
         e.set_band(a, b - a)
         bands.append((e, a, b - a))
     rows = [whole.band_rows(a, c) for _, a, c in bands]
     stride = (whole.band_chunk_bytes(max(r1 - r0 for r0, r1 in rows), halo_rows) + 255) & ~255
     chunks = [torch.zeros(stride * items, dtype=torch.uint8, device="cuda") for _ in bands]
     torch.cuda.synchronize()
-    refs = [orc.Encoder(w, h, qp=qp, n_slices=n_slices, keyint=keyint, threads=8) for _ in range(items)]
+    refs = [orc.Encoder(w, h, qp=qp, n_slices=n_slices, keyint=keyint, threads=8, deblock=deblock) for _ in range(items)]
     for t in range(n):
         idr = t % keyint == 0
         slots = [2 * i + (t & 1) for i in range(items)]
