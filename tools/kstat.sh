@@ -15,7 +15,7 @@ PY
 if [ -n "$KSTAT_KERNEL" ]; then python3 - $O $KSTAT_KERNEL <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/prof/*/*kernel_trace.csv")[0]
-d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(sys.argv[2]))
+d = sorted((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if sys.argv[2] in r["Kernel_Name"])
 n = len(d)
 print(sys.argv[2], "n", n, "min %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f" % (d[0], d[n // 10], d[n // 2], d[9 * n // 10], d[-1]))
 print(" ".join("%.0f" % x for x in d[:: max(1, n // 40)]))

@@ -215,7 +215,9 @@ static int entropy_flush(venc_ctx *c);
 static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, const venc_bufs &b, const venc_step &S, int n_items, int planes) {
     int max_rows = 1;
     for (int s = S.slice0; s < S.slice1; s++) max_rows = c->slice_rows[s + 1] - c->slice_rows[s] > max_rows ? c->slice_rows[s + 1] - c->slice_rows[s] : max_rows;
-    const int waves = max_rows < DBK_MAX_WAVES ? max_rows : DBK_MAX_WAVES;
+    static const int cap = getenv("VENC_DBK_WAVES") ? atoi(getenv("VENC_DBK_WAVES")) : DBK_MAX_WAVES; /* (diagnostic: fewer rows at a time) */
+    const int wmax = cap >= 1 && cap < DBK_MAX_WAVES ? cap : DBK_MAX_WAVES;
+    const int waves = max_rows < wmax ? max_rows : wmax;
     prof_begin(c, KID_DEBLOCK, st);
     hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), 0, st, g, b, S, planes);
     prof_end(c, st);
