@@ -106,8 +106,8 @@ typedef struct x264_param_t {
          * ncclAllGather).  pf_exchange, when set, takes precedence. */
         int i_rccl_world, i_rccl_rank, i_halo_rows;
         unsigned char rccl_id[128];
-        /* Intra16x16 prediction of I pictures: 1 (x264_param_default_preset's default, like libx264's presets) = vertical /
-         * horizontal / DC chosen per macroblock by SAD; 0 = DC only (the codec definition of round 1, what bench.py measures) */
+        /* Intra16x16 prediction of I pictures: 2 (x264_param_default_preset's default, like libx264's presets) = vertical /
+         * horizontal / DC / plane chosen per macroblock by SAD; 1 = without plane; 0 = DC only (the codec definition of round 1, what bench.py measures) */
         int i_intra_modes;
         /* sub-sample refinement of the motion vectors (libx264's analyse.i_subpel_refine, which the reference leaves to its
          * preset, av_encode.c:365): 0 = integer-sample vectors (what bench.py measures), 1 = half-sample, 2 = half- then

@@ -53,7 +53,7 @@ typedef struct {
     int idr_base;        /* index of the first closed GOP (idr_pic_id = (idr_base + n) & 1): lets a
                             GOP-sharded run reproduce the single-encoder stream */
     int rc_mode;         /* 0: fixed QP; 1: picture QP by spec/CODEC.md section 1a (qp = the base QP) */
-    int intra_modes;     /* 0: Intra16x16 DC prediction only; 1: vertical / horizontal / DC chosen by SAD (spec/CODEC.md section 3) */
+    int intra_modes;     /* 0: Intra16x16 DC prediction only; 1: vertical / horizontal / DC chosen by SAD; 2: plane as well (spec/CODEC.md section 3) */
     int deblock;         /* 0: disable_deblocking_filter_idc = 1; 1: in-loop filter inside every slice (idc 2; spec/CODEC.md section 5a) */
     int subpel;          /* 0: integer-sample vectors; 1: half-sample refinement; 2: half then quarter (spec/CODEC.md section 2a) */
 } orc_params;

@@ -465,7 +465,6 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             if (st == 0) FAIL(d, "intra MB in P slice unsupported");
             if (t < 1 || t > 24) FAIL(d, "mb_type %d unsupported in I slice", t);
             int pm = (t - 1) & 3, cbpc = ((t - 1) >> 2) % 3, acf = (t - 1) >= 12;
-            if (pm == 3) FAIL(d, "Intra16x16 plane prediction unsupported");
             if (br_ue(b) != 0) FAIL(d, "intra chroma pred mode unsupported");
             qp += br_se(b);
             int16_t dcl[16], ac[16][16];
@@ -495,6 +494,25 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
             } else if (pm == 1) {
                 if (!aL) FAIL(d, "Intra16x16 horizontal prediction without a macroblock to the left (mb %d)", mb);
                 for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, dst[(size_t)y * d->cw - 1], 16);
+            } else if (pm == 3) {
+                /* plane (8.3.3.4): p[x, -1], p[-1, y] and the corner p[-1, -1] as arrays indexed from -1 */
+                if (!aT || !aL || !mb_avail(d, mx - 1, my - 1, sid)) FAIL(d, "Intra16x16 plane prediction without its neighbours (mb %d)", mb);
+                int tp[17], lf[17];
+                for (int i = -1; i < 16; i++) {
+                    tp[i + 1] = dst[-(ptrdiff_t)d->cw + i];
+                    lf[i + 1] = i < 0 ? dst[-(ptrdiff_t)d->cw - 1] : dst[(size_t)i * d->cw - 1];
+                }
+                int hh = 0, vv = 0;
+                for (int k = 0; k <= 7; k++) {
+                    hh += (k + 1) * (tp[1 + 8 + k] - tp[1 + 6 - k]);
+                    vv += (k + 1) * (lf[1 + 8 + k] - lf[1 + 6 - k]);
+                }
+                const int pa = 16 * (lf[16] + tp[16]), pb = (5 * hh + 32) >> 6, pc = (5 * vv + 32) >> 6;
+                for (int y = 0; y < 16; y++)
+                    for (int x = 0; x < 16; x++) {
+                        const int v = (pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5;
+                        pred16[16 * y + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+                    }
             } else
                 memset(pred16, dcp, 256);
             /* luma DC: inverse zig-zag, 4x4 Hadamard, scaling (8.5.10) */

@@ -667,7 +667,28 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
         long best = sad[2];
         for (int m = 1; m >= 0; m--)
             if (sad[m] >= 0 && sad[m] <= best) best = sad[m], mode = m;
-        if (mode == 0)
+        /* intra_modes = 2: plane prediction (8.3.3.4) as a fourth candidate when the left, upper and upper-left macroblocks are
+         * in the slice; chosen only when strictly better (ties go to the smaller mode number) */
+        uint8_t plane16[256];
+        if (e->p.intra_modes >= 2 && avail_l && avail_t) {
+            const uint8_t *top = rec - (ptrdiff_t)e->cw; /* top[-1] is the corner sample */
+            int H = 0, V = 0;
+            for (int k = 0; k < 8; k++) {
+                H += (k + 1) * ((int)top[8 + k] - (int)top[6 - k]);
+                V += (k + 1) * ((int)rec[(size_t)(8 + k) * e->cw - 1] - (k == 7 ? (int)top[-1] : (int)rec[(size_t)(6 - k) * e->cw - 1]));
+            }
+            const int a = 16 * ((int)rec[(size_t)15 * e->cw - 1] + (int)top[15]), b = (5 * H + 32) >> 6, c = (5 * V + 32) >> 6;
+            long s3 = 0;
+            for (int y = 0; y < 16; y++)
+                for (int x = 0; x < 16; x++) {
+                    plane16[16 * y + x] = clip_u8((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
+                    s3 += abs((int)cur[(size_t)y * e->cw + x] - (int)plane16[16 * y + x]);
+                }
+            if (s3 < best) best = s3, mode = 3;
+        }
+        if (mode == 3)
+            memcpy(pred16, plane16, 256);
+        else if (mode == 0)
             for (int y = 0; y < 16; y++) memcpy(pred16 + 16 * y, rec - (ptrdiff_t)e->cw, 16);
         else if (mode == 1)
             for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, rec[(size_t)y * e->cw - 1], 16);
@@ -915,7 +936,7 @@ static void write_mb_intra(orc_enc *e, bw_t *b, int mx, int my, int srow) {
     int mb = my * e->mbw + mx;
     const int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     int cbp = e->mb_cbp[mb], cbpc = cbp >> 4, acf = (cbp & 15) != 0;
-    bw_ue(b, (uint32_t)(1 + e->mb_i16mode[my * e->mbw + mx] + 4 * cbpc + 12 * acf)); /* mb_type, table 7-11: Intra16x16PredMode 0 V, 1 H, 2 DC */
+    bw_ue(b, (uint32_t)(1 + e->mb_i16mode[my * e->mbw + mx] + 4 * cbpc + 12 * acf)); /* mb_type, table 7-11: Intra16x16PredMode 0 V, 1 H, 2 DC, 3 plane */
     bw_ue(b, 0);                                                   /* intra_chroma_pred_mode = DC */
     bw_se(b, 0);                                                   /* mb_qp_delta */
     cavlc_block(b, lv + 16 * 16, 16, luma_nc(e, mx, my, 0, 0, srow));

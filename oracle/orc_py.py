@@ -96,7 +96,7 @@ class Encoder:
         intra_modes: Intra16x16 vertical / horizontal / DC by SAD instead of DC only.
         subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a)."""
         self.L = lib()
-        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(bool(intra_modes)), int(bool(deblock)), int(subpel))
+        self.params = OrcParams(width, height, qp, n_slices, keyint, fps[0], fps[1], sar[0], sar[1], threads, idr_base, int(bool(rc)), int(intra_modes), int(bool(deblock)), int(subpel))
         self.h = self.L.orc_enc_open(C.byref(self.params))
         if not self.h:
             raise ValueError("orc_enc_open rejected the parameters")

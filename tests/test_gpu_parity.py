@@ -434,7 +434,7 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
     # the C driver opens the encoder as the reference does: X264_RC_CRF (av_encode.c:400-401) = spec/CODEC.md section 1a
     # ... and with the preset's intra modes (x264_param_default_preset: Intra16x16 V / H / DC)
     # ... and its sub-sample refinement (every preset but ultrafast: half- then quarter-sample stage)
-    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True, subpel=2, deblock=True)
+    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=2, subpel=2, deblock=True)
     dec = orc.Decoder()
     got = samples_of(data, t)
     for k, f in enumerate(frames):
@@ -584,7 +584,7 @@ def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path)
     assert pct == sorted(pct) and pct[-1] <= 100.0 and pct[-1] > 50.0
     t = read_track(open(mp4, "rb").read())
     assert len(t["stsz"]) == 9 and t["stss"] == [1, 6] and t["timescale"] == 25
-    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=True, subpel=2, deblock=True)
+    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=2, subpel=2, deblock=True)
     got = samples_of(open(mp4, "rb").read(), t)
     for k in range(9):
         ref = enc.encode(*frames[k])
@@ -693,6 +693,37 @@ def test_intra16x16_vertical_horizontal_dc_match_oracle(venc, orc, w, h, qp, sli
         modes |= set(int(x) for x in (eng.debug(2)[:, 25] >> 1) & 3)
     if w >= 176 and h >= 144:
         assert modes == {0, 1, 2}, modes     # every predictor was chosen somewhere
+    eng.close()
+
+
+@pytest.mark.parametrize("w,h,qp,slices", [(176, 144, 26, 2), (352, 288, 30, 3), (178, 146, 22, 1), (1920, 1080, 28, 8)])
+def test_intra16x16_plane_prediction_matches_oracle(venc, orc, w, h, qp, slices):
+    """Intra16x16 plane prediction as the fourth candidate (intra_modes = 2, spec/CODEC.md section 3): smooth gradients with a
+    little texture, where the plane predictor wins in places; levels, reconstruction and slice RBSPs against the oracle; all-I"""
+    enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=1, threads=8, intra_modes=2)
+    eng = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2, intra_modes=2)
+    yy, xx = np.mgrid[0:h, 0:w]
+    modes = set()
+    for t in range(3):
+        tex = venc.synth_frame(w, h, t, 21)
+        y = (40 + (1.1 + 0.2 * t) * xx * 200.0 / w + 0.8 * yy * 160.0 / h + 12 * np.sin((xx + 2 * yy + 5 * t) / 11.0)).clip(0, 255).astype(np.uint8)
+        y[:, w // 2:] = tex[0][:, w // 2:]      # half gradient, half texture
+        u, v = tex[1], tex[2]
+        ref = enc.encode(y, u, v)
+        eng.upload(t % 2, y, u, v)
+        eng.encode_step([t % 2], [t % 2], True, 0, [t & 1])
+        eng.sync()
+        lv_g, lv_o = eng.debug(1), enc.levels()
+        if not np.array_equal(lv_g, lv_o):
+            bad = np.argwhere(lv_g != lv_o)
+            raise AssertionError("levels frame %d: first mismatch mb,blk,idx=%s gpu=%d orc=%d (%d diffs)" % (
+                t, bad[0], lv_g[tuple(bad[0])], lv_o[tuple(bad[0])], len(bad)))
+        for p in range(3):
+            assert np.array_equal(eng.debug(4 + p), enc.recon()[p]), "recon plane %d frame %d" % (p, t)
+        sl_o = [unescape(b) for (ty, _, b) in split_nals(ref.data) if ty in (1, 5)]
+        assert eng.get_slices(t % 2) == sl_o, "slices frame %d" % t
+        modes |= set(int(x) for x in (eng.debug(2)[:, 25] >> 1) & 3)
+    assert 3 in modes, modes
     eng.close()
 
 

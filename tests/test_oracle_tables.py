@@ -195,3 +195,26 @@ def test_cavlc_published_known_answers_product_device_function(hc, levels, want)
     out = np.zeros(64, np.uint8)
     n = hc.hc_cavlc_block(c.ctypes.data, 0, 16, 0, out.ctypes.data, 64)
     assert "".join("{:08b}".format(b) for b in out)[:n] == want
+
+
+def test_plane_prediction_reproduces_a_plane():
+    """Intra16x16 plane prediction (8.3.3.4) of a picture that IS a plane: away from the first row and column of macroblocks the
+    predictor is chosen and leaves (almost) nothing to code; the decoder agrees (PARITY UNPINNED: no external vector)"""
+    import numpy as np
+    from oracle import orc_py
+    w, h = 96, 80
+    yy, xx = np.mgrid[0:h, 0:w]
+    y = (20 + 1.5 * xx + 0.75 * yy).astype(np.uint8)
+    c = np.full((h // 2, w // 2), 128, np.uint8)
+    a = orc_py.Encoder(w, h, qp=20, n_slices=1, keyint=1, intra_modes=1)
+    b = orc_py.Encoder(w, h, qp=20, n_slices=1, keyint=1, intra_modes=2)
+    d = orc_py.Decoder()
+    fa, fb = a.encode(y, c, c), b.encode(y, c, c)
+    assert len(fb.data) < len(fa.data)
+    lv = b.levels()
+    inner = [my * b.mbw + mx for my in range(1, b.mbh) for mx in range(1, b.mbw)]
+    assert sum(int(np.count_nonzero(lv[m, :17])) for m in inner) <= len(inner)   # at most a stray level per macroblock
+    assert d.decode(fb.data) == 1
+    for p, q in zip(b.recon(), d.planes()):
+        assert np.array_equal(p, q)
+    assert np.abs(b.recon()[0][:h, :w].astype(int) - y.astype(int)).max() <= 6

@@ -19,13 +19,13 @@ timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 timeout -k 10 300 python bench.py --workload 2160p $Q > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
 timeout -k 10 300 python bench.py --serial-steps $Q > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
 # the optional coding tools (each checked bit-exact against the oracle on the first GOP), 1080p and for sub-sample refinement 2160p
-for v in "crf:--crf 26" "intra_modes:--intra-modes" "subpel1:--subpel 1" "subpel2:--subpel 2" "deblock:--deblock" "all_tools:--crf 26 --intra-modes --subpel 2 --deblock" "preset_tools_no_filter:--crf 26 --intra-modes --subpel 2"; do
+for v in "crf:--crf 26" "intra_modes:--intra-modes" "subpel1:--subpel 1" "subpel2:--subpel 2" "deblock:--deblock" "intra_modes_plane:--intra-modes 2" "all_tools:--crf 26 --intra-modes 2 --subpel 2 --deblock" "preset_tools_no_filter:--crf 26 --intra-modes 2 --subpel 2"; do
   timeout -k 10 300 python bench.py --no-extras --cpu-frames 30 ${v#*:} > $O/bench_tool_${v%%:*}.json 2> $O/bench_tool_${v%%:*}.err; cut -c1-160 $O/bench_tool_${v%%:*}.json
 done
 timeout -k 10 300 python bench.py --workload 2160p --no-extras --cpu-frames 0 --subpel 2 > $O/bench_tool_subpel2_2160p.json 2> $O/bench_tool_subpel2_2160p.err
 # sub-sample mode and the in-loop filter: kernel stats, every kernel alone on the chip
 cd /tmp
-VENC_NO_OVERLAP=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_tools -- python3 $R/bench.py --steps 2 --warmup 1 $Q --no-profile --subpel 2 --deblock --crf 26 --intra-modes > $O/stats_tools.log 2>&1
+VENC_NO_OVERLAP=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_tools -- python3 $R/bench.py --steps 2 --warmup 1 $Q --no-profile --subpel 2 --deblock --crf 26 --intra-modes 2 > $O/stats_tools.log 2>&1
 cd $R
 cd /tmp
 for wl in 1080p 2160p; do

@@ -341,7 +341,7 @@ class Engine:
         subpel: 0 integer-sample vectors, 1 half-sample refinement, 2 half then quarter (spec/CODEC.md section 2a).
         deblock: in-loop deblocking filter inside every slice (spec/CODEC.md section 5a)."""
         self.L = lib if lib is not None else hip_lib()
-        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)), int(bool(intra_modes)), int(bool(deblock)), int(subpel))
+        self.cfg = VencConfig(width, height, qp, n_slices, max_items, in_slots, out_slots, device, int(bool(rc)), int(intra_modes), int(bool(deblock)), int(subpel))
         h = C.c_void_p()
         rc = self.L.venc_open(C.byref(self.cfg), C.byref(h))
         if rc != 0:
@@ -501,7 +501,7 @@ class X264Encoder:
         p.hip.i_slice_first, p.hip.i_slice_count = slice_first, slice_count
         # Intra16x16 V / H / DC by SAD: the C API's preset default is on; this mirror defaults to the DC-only codec
         # definition that bench.py and the golden fixtures are frozen on
-        p.hip.i_intra_modes = int(bool(intra_modes))
+        p.hip.i_intra_modes = int(intra_modes)
         p.hip.i_subpel = int(subpel)  # (likewise: the C API's presets refine to quarter samples)
         p.hip.i_deblock = int(bool(deblock))  # (and filter in the loop)
         if rccl is not None:

@@ -368,6 +368,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     fill_qparams(&g.qc, cfg->qp < 30 ? cfg->qp : h_qpc_hi[cfg->qp - 30]);
     c->cfg.n_slices = g.n_slices;
     g.subpel = cfg->subpel < 0 ? 0 : cfg->subpel > 2 ? 2 : cfg->subpel;
+    g.intra_plane = cfg->intra_modes >= 2;
     c->g_idr = g;
     g.slice_base = g.mbh / g.n_slices;
     g.slice_rem = g.mbh % g.n_slices;

@@ -62,6 +62,7 @@ typedef struct {
     int n_slices;
     int slice_base, slice_rem; /* bands: the first slice_rem slices have slice_base+1 MB rows, the rest slice_base */
     int qp;
+    int intra_plane; /* Intra16x16 plane prediction is a candidate (intra_modes = 2) */
     int subpel; /* 0: vectors in integer samples; 1, 2: P pictures refine them (k_subpel) and every vector of the step is in QUARTER samples */
     venc_qparams ql, qc;
 } venc_geom;

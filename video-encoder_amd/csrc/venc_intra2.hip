@@ -425,6 +425,8 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
         const int my = cb + rw;
         const int steps = g.mbw + nr - 1;
         uint32_t left4 = 0;                      /* luma lanes: the four samples left of this lane's block rows */
+        uint32_t lcol[4] = {0, 0, 0, 0};         /* plane prediction: the whole column left of the macroblock, and the corner sample */
+        uint32_t corner = 0;
         int leftY = 0, leftC0 = 0, leftC1 = 0;   /* sums of the left column (luma: all 16; chroma: upper / lower half of this lane's plane) */
         const bool cur_al = luma ? ((g.w & 3) == 0) : ((g.w & 7) == 0);
         const int pyl = (luma ? my * 16 : my * 8) + by;
@@ -479,12 +481,44 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                         sD = __builtin_amdgcn_sad_u8(cq[y], d4, sD);
                     }
                 }
+                /* plane prediction (8.3.3.4; intra_modes = 2): every luma lane holds the row above (tb), the column to the left
+                 * (lcol) and the corner, so the two gradients need no exchange; the lane predicts its own 4x4 block */
+                uint32_t sP = 0;
+                int pl[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) pl[i] = 0;
+                const bool try_plane = g.intra_plane && aL && aT; /* (uniform per half-wave row; lanes of both rows run the code) */
+                if (g.intra_plane) {
+                    int H = 0, V = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++) {
+                        const int hi = 8 + kk, lo = 6 - kk;
+                        const int th = (int)((tb[hi >> 2] >> (8 * (hi & 3))) & 255u), tl = lo >= 0 ? (int)((tb[lo >> 2] >> (8 * (lo & 3))) & 255u) : (int)corner;
+                        const int lh = (int)((lcol[hi >> 2] >> (8 * (hi & 3))) & 255u), ll = lo >= 0 ? (int)((lcol[lo >> 2] >> (8 * (lo & 3))) & 255u) : (int)corner;
+                        H += (kk + 1) * (th - tl), V += (kk + 1) * (lh - ll);
+                    }
+                    const int pa = 16 * ((int)(lcol[3] >> 24) + (int)(tb[3] >> 24)), pb = (5 * H + 32) >> 6, pc = (5 * V + 32) >> 6;
+                    if (luma) {
+#pragma unroll
+                        for (int y = 0; y < 4; y++) {
+                            uint32_t row = 0;
+#pragma unroll
+                            for (int x = 0; x < 4; x++) {
+                                pl[4 * y + x] = venc_clip_u8((pa + pb * (bx + x - 7) + pc * (by + y - 7) + 16) >> 5);
+                                row |= (uint32_t)pl[4 * y + x] << (8 * x);
+                            }
+                            sP = __builtin_amdgcn_sad_u8(cq[y], row, sP);
+                        }
+                    }
+                    sP = half_sum32(sP, lane);
+                }
                 sV = half_sum32(sV, lane), sH = half_sum32(sH, lane), sD = half_sum32(sD, lane);
                 int mode = 2;
                 {
                     uint32_t best = sD;
                     if (aL && sH <= best) best = sH, mode = 1;
                     if (aT && sV <= best) best = sV, mode = 0;
+                    if (try_plane && sP < best) best = sP, mode = 3; /* (ties go to the smaller mode number) */
                 }
                 const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
                 int c[16], p[16];
@@ -493,7 +527,7 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
 #pragma unroll
                     for (int x = 0; x < 4; x++) {
                         c[4 * y + x] = (int)((cq[y] >> (8 * x)) & 255u);
-                        p[4 * y + x] = !luma || mode == 2 ? pred : mode == 0 ? (int)((top4 >> (8 * x)) & 255u) : (int)((left4 >> (8 * y)) & 255u);
+                        p[4 * y + x] = !luma || mode == 2 ? pred : mode == 3 ? pl[4 * y + x] : mode == 0 ? (int)((top4 >> (8 * x)) & 255u) : (int)((left4 >> (8 * y)) & 255u);
                     }
 #pragma unroll
                 for (int y = 0; y < 4; y++) cq[y] = nq[y];
@@ -532,6 +566,8 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                 const uint32_t c0 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 0)), c1 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 1));
                 const uint32_t c2 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 2)), c3 = (uint32_t)__shfl((int)prq, hbase | blk_of(3, 3));
                 left4 = by == 0 ? c0 : by == 4 ? c1 : by == 8 ? c2 : c3;
+                lcol[0] = c0, lcol[1] = c1, lcol[2] = c2, lcol[3] = c3;
+                corner = tb[3] >> 24; /* the last sample above this macroblock is the corner of the next */
                 leftY = (int)__builtin_amdgcn_sad_u8(c3, 0u, __builtin_amdgcn_sad_u8(c2, 0u, __builtin_amdgcn_sad_u8(c1, 0u, __builtin_amdgcn_sad_u8(c0, 0u, 0u))));
                 const int rcb0 = __shfl(pr, hbase | 17), rcb1 = __shfl(pr, hbase | 19), rcr0 = __shfl(pr, hbase | 21), rcr1 = __shfl(pr, hbase | 23);
                 leftC0 = plane == 2 ? rcr0 : rcb0;
