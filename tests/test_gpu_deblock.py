@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
     (64, 48, 44, 1, 0, 3, "noise"),
     (1920, 1080, 30, 8, 0, 3, "synth"),
     (640, 1104, 36, 2, 0, 2, "noise"),     # 35-row slices: more rows than waves in a block
+    (16, 16, 40, 1, 2, 3, "noise"),        # one macroblock: internal edges only, every sub-sample window on the rim
+    (1920, 1080, 34, 1, 0, 2, "synth"),    # one slice of 68 rows: five rounds of the block's waves
+    (3840, 2160, 30, 8, 2, 2, "synth"),    # BASELINE config 3 geometry with refinement and filter
 ])
 def test_deblocked_pictures_match_oracle_stage_by_stage(venc, orc, w, h, qp, slices, subpel, n, kind):
     enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=30, threads=8, subpel=subpel, deblock=True)

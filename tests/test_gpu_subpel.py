@@ -25,6 +25,8 @@ def _clip(venc, kind, w, h, n):
     (352, 288, 22, 4, 2, "synth", 4),        # vectors up to +-16 at the picture edges
     (64, 48, 34, 1, 2, "half", 3),
     (1920, 1080, 26, 8, 2, "synth", 3),
+    (16, 16, 30, 1, 2, "half", 3),          # one macroblock: every window leaves the picture
+    (7680, 4320, 32, 8, 2, "synth", 2),     # the largest geometry of the parity tests
 ])
 def test_refined_p_pictures_match_oracle_stage_by_stage(venc, orc, w, h, qp, slices, subpel, kind, n):
     enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=30, threads=8, subpel=subpel)
