@@ -30,7 +30,9 @@
  * of outputs two samples apart takes its six taps from six such registers; b1 and h1 fit 16 bits (-2550 .. 10710); only
  * j -- the six-tap of six b1 -- needs 32.  Positions whose taps leave the picture use clamped coordinates, as the
  * standard does; k_subpel reads the planes only where the needed samples lie inside the picture. */
+#ifndef HP_ROWS
 #define HP_ROWS 16
+#endif
 typedef short hp_s2 __attribute__((ext_vector_type(2)));
 DEVFN hp_s2 hp_even(uint32_t w) { return __builtin_bit_cast(hp_s2, w & 0x00ff00ffu); }
 DEVFN hp_s2 hp_odd(uint32_t w) { return __builtin_bit_cast(hp_s2, (w >> 8) & 0x00ff00ffu); }
