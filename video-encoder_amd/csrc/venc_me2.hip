@@ -304,7 +304,9 @@ __global__ __launch_bounds__(512) void k_me_tile(venc_geom g, venc_bufs B, venc_
 #define FIX_WD 13 /* window row: 48 bytes + 4 spare, in dwords */
 #define FIX_NDY 9   /* vertical displacements per wave: 4 waves cover 36 >= 33.  (8 waves x 5: k_me_fix 17 -> 26 us per launch, 1080p 149 -> 143
                        Gpx/s; 16 x 3 spills at the 128-register cap of a 1024-thread block.  Every wave pays the 64 LDS reads of the
-                       current block and the block-wide barriers whatever its share of the search.) */
+                       current block and the block-wide barriers whatever its share of the search.  Also tried: five waves, columns -16 .. 15 as
+                       half-waves of five displacements each and the column +16 on a wave of its own -- 20 window rows and 320 SADs per
+                       lane instead of 24 and 576, no idle lanes: 17 -> 28 us per launch, 1080p 151 -> 143 Gpx/s.) */
 #define FIX_WAVES 4
 
 template <bool RC> /* rate-control variant, as k_me_pool's */
