@@ -265,27 +265,34 @@ __global__ __launch_bounds__(256) void k_subpel(venc_geom g, venc_bufs B, venc_s
         src[it] = (p == 0 ? ref : hpl + (size_t)(p - 1) * plane) + (size_t)r * g.cw + 4 * dw;
         dst[it] = p * SP_PD + r * (SP_PS / 4) + dw;
     }
+    /* the records and the current samples of the wave's macroblocks: loaded up front, so that a macroblock's round starts
+     * with ONE level of loads (its plane pieces) instead of three in a row (record -> addresses -> pieces) */
+    uint32_t mrec[SP_K];
+#pragma unroll
+    for (int kmb = 0; kmb < SP_K; kmb++) {
+        const int mb_raw = S.mb0 + ((int)blockIdx.x * 4 + wave) * SP_K + kmb, mbc = min(mb_raw, S.mb1 - 1);
+        mrec[kmb] = B.mvsad[(size_t)item * g.nmb + mbc];
+        const int px = (mbc % g.mbw) * 16 + x4, py = (mbc / g.mbw) * 16 + y;
+        uint32_t cur4; /* display edges replicate (spec section 1) */
+        if ((g.w & 3) == 0 && px + 4 <= pw && py < ph)
+            cur4 = *(const uint32_t *)(cur + (size_t)py * cstride + px);
+        else {
+            const uint8_t *row = cur + (size_t)min(py, ph - 1) * cstride;
+            cur4 = (uint32_t)row[min(px, pw - 1)] | ((uint32_t)row[min(px + 1, pw - 1)] << 8) | ((uint32_t)row[min(px + 2, pw - 1)] << 16) |
+                   ((uint32_t)row[min(px + 3, pw - 1)] << 24);
+        }
+        L.cur[kmb][lane] = cur4;
+    }
+#pragma unroll
     for (int kmb = 0; kmb < SP_K; kmb++) {
         const int mb_raw = S.mb0 + ((int)blockIdx.x * 4 + wave) * SP_K + kmb;
         if (mb_raw >= S.mb1) break; /* (wave-uniform) */
         const int mb = mb_raw, mx = mb % g.mbw, my = mb / g.mbw;
         /* (one macroblock per wave: its record is uniform -- said aloud, so that the stages' control flow stays on the
          * scalar unit) */
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)B.mvsad[(size_t)item * g.nmb + mb]);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)mrec[kmb]);
         const int dx = (int)(int8_t)(m & 255u), dy = (int)(int8_t)((m >> 8) & 255u); /* the full search's vector, integer samples */
         const int x0 = mx * 16 + dx, y0 = my * 16 + dy;
-        {   /* the current macroblock; display edges replicate (spec section 1) */
-            const int px = mx * 16 + x4, py = my * 16 + y;
-            uint32_t cur4;
-            if ((g.w & 3) == 0 && px + 4 <= pw && py < ph)
-                cur4 = *(const uint32_t *)(cur + (size_t)py * cstride + px);
-            else {
-                const uint8_t *row = cur + (size_t)min(py, ph - 1) * cstride;
-                cur4 = (uint32_t)row[min(px, pw - 1)] | ((uint32_t)row[min(px + 1, pw - 1)] << 8) | ((uint32_t)row[min(px + 2, pw - 1)] << 16) |
-                       ((uint32_t)row[min(px + 3, pw - 1)] << 24);
-            }
-            L.cur[kmb][lane] = cur4;
-        }
         int sh = 0;
         if (x0 >= 1 && x0 + 17 <= g.cw && y0 >= 1 && y0 + 17 <= g.ch) {
             /* rows y0 - 1 .. y0 + 16, columns from the aligned dword that holds x0 - 1: 6 dwords cover sh + 18 samples.
