@@ -567,6 +567,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         venc_close(c);
         return -1;
     }
+    if (cfg->deblock && g.slice_base + 1 > DBK_MAX_ROWS) { /* (the rows' progress flags live in the block's LDS) */
+        SET_ERR("venc_open: the in-loop filter handles slices of up to %d macroblock rows (this picture: %d per slice; use more slices)", DBK_MAX_ROWS, g.slice_base + 1);
+        venc_close(c);
+        return -1;
+    }
     if (g.subpel && (c->me_mode != 0 || c->inter_legacy)) {
         SET_ERR("venc_open: sub-sample refinement runs behind the shipped search and transform only (VENC_ME / VENC_INTER select test kernels)");
         venc_close(c);
