@@ -42,6 +42,7 @@ struct dbk_tile {
     uint32_t y[20 * 5];     /* rows -4 .. 15, columns -4 .. 15 */
     uint32_t c[2][12 * 3];  /* Cb, Cr: rows -4 .. 7, columns -4 .. 7 */
     uint32_t bs[8];         /* strengths as bytes: [direction][edge][segment] */
+    uint32_t info[3][9];    /* the records of this macroblock, its left and its upper neighbour: 8 dwords of venc_mbinfo + the vector word */
 };
 
 /* one line across an edge: s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (chroma: p1 p0 q0 q1 in s[2..5]); 8.7.2.3 / 8.7.2.4 */
@@ -97,53 +98,88 @@ __global__ __launch_bounds__(64 * DBK_MAX_WAVES) void k_deblock(venc_geom g, ven
     const bool chroma = lane_c;
     const int alpha = chroma ? c_dbk_alpha[qpc] : c_dbk_alpha[qp], beta = chroma ? c_dbk_beta[qpc] : c_dbk_beta[qp];
     const uint32_t tcw = *(const uint32_t *)c_dbk_tc0[chroma ? qpc : qp];
+    /* Memory instructions: few of them, few lanes each, wide -- one load for the records of a macroblock and the one above
+     * (the left one's is last round's own), rows as 16-byte / 8-byte pieces, the left neighbour's last four columns carried
+     * over in LDS, the columns to the left / rows above stored only when the edge next to them was filtered.  (First
+     * version: six byte-wise loads of 32 lanes for the strengths and three dword loads / stores of 64 + 16 + 16 lanes per
+     * plane and macroblock; this shape: 443 -> 421 us per luma launch at 1080p x 10 -- the memory instructions are not what
+     * makes nine rows on one CU 3.4 times slower per macroblock than one) */
     for (int rl = wv; rl < nrows; rl += nw) {
         const int my = r0 + rl;
+        const bool aT = rl > 0;
+        bool left_in_tile = false; /* the tile holds the left neighbour's filtered samples (it had an edge to filter) */
         for (int mx = 0; mx < g.mbw; mx++) {
-            if (rl > 0) { /* the row above is two macroblocks ahead (or finished) */
+            if (aT) { /* the row above is two macroblocks ahead (or finished) */
                 const int need = min(mx + 2, g.mbw);
                 while (__builtin_amdgcn_readfirstlane(((volatile int *)s_prog)[rl - 1]) < need) __builtin_amdgcn_s_sleep(1);
                 __threadfence_block();
             }
             const int mb = my * g.mbw + mx;
-            const bool aL = mx > 0, aT = rl > 0;
+            const bool aL = mx > 0;
+            /* ---- records: ONE load, lanes 0-8 this macroblock (8 dwords + vector), lanes 9-17 the one above; the left one is
+             * last round's own ---- */
+            if (lane < 9) T.info[1][lane] = T.info[0][lane]; /* (garbage for mx = 0: never read, aL is false) */
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 18) {
+                const int which = lane >= 9, k = lane - 9 * which; /* k < 8: record dword, 8: the vector */
+                const int m2 = which ? (aT ? mb - g.mbw : mb) : mb;
+                const uint32_t v = k < 8 ? ((const uint32_t *)(infos + m2))[k] : mvs[m2];
+                T.info[which ? 2 : 0][k] = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
             /* ---- strengths: lane = direction * 16 + edge * 4 + segment ---- */
             int bs = 0;
             if (lane < 32) {
                 const int dir = lane >> 4, e = (lane >> 2) & 3, seg = lane & 3;
                 if (e > 0 || (dir ? aT : aL)) {
-                    const int mbp = e ? mb : (dir ? mb - g.mbw : mb - 1);
+                    const int nb = e ? 0 : (dir ? 2 : 1); /* the record of the block on the p side */
                     const int bq = dir ? 4 * e + seg : 4 * seg + e;
                     const int bp = e ? (dir ? 4 * (e - 1) + seg : 4 * seg + e - 1) : (dir ? 12 + seg : 4 * seg + 3);
-                    if ((infos[mb].flags | infos[mbp].flags) & 1)
+                    const uint8_t *own = (const uint8_t *)T.info[0], *oth = (const uint8_t *)T.info[nb];
+                    if ((own[25] | oth[25]) & 1) /* venc_mbinfo.flags */
                         bs = e ? 3 : 4;
-                    else if (infos[mb].nnz[bq] | infos[mbp].nnz[bp])
+                    else if (own[bq] | oth[bp])
                         bs = 2;
                     else if (e == 0) {
-                        const uint32_t a = mvs[mb], b = mvs[mbp];
+                        const uint32_t a = T.info[0][8], b = T.info[nb][8];
                         const int ddx = (int)(int8_t)(a & 255u) - (int)(int8_t)(b & 255u), ddy = (int)(int8_t)((a >> 8) & 255u) - (int)(int8_t)((b >> 8) & 255u);
                         bs = (abs(ddx) >= mvthr || abs(ddy) >= mvthr) ? 1 : 0;
                     }
                 }
             }
-            if (__ballot(bs != 0) != 0ull) {
+            const bool any = __ballot(bs != 0) != 0ull;
+            if (any) {
                 if (lane < 32) ((uint8_t *)T.bs)[lane] = (uint8_t)bs;
-                /* ---- tile ---- */
+                /* ---- tile: rows as 16-byte (luma) / 8-byte (chroma) pieces; the columns to the left from the old tile when it
+                 * holds them ---- */
+                uint32_t ly = 0, lc = 0;
+                if (left_in_tile) {
+                    if (do_y && lane < 16) ly = T.y[(4 + lane) * 5 + 4];
+                    if (do_c && lane < 16) lc = T.c[lane >> 3][(4 + (lane & 7)) * 3 + 2];
+                } else if (aL) {
+                    if (do_y && lane < 16) ly = *(const uint32_t *)(py + (size_t)(my * 16 + lane) * ystride + mx * 16 - 4);
+                    if (do_c && lane < 16) lc = *(const uint32_t *)(((lane >> 3) ? pc1 : pc0) + (size_t)(my * 8 + (lane & 7)) * cstride + mx * 8 - 4);
+                }
+                __builtin_amdgcn_wave_barrier();
                 if (do_y) {
-                    T.y[(4 + (lane >> 2)) * 5 + 1 + (lane & 3)] = *(const uint32_t *)(py + (size_t)(my * 16 + (lane >> 2)) * ystride + mx * 16 + 4 * (lane & 3));
-                    if (lane < 16) T.y[(4 + lane) * 5] = aL ? *(const uint32_t *)(py + (size_t)(my * 16 + lane) * ystride + mx * 16 - 4) : 0u;
-                    else if (lane < 32) T.y[((lane - 16) >> 2) * 5 + 1 + (lane & 3)] = aT ? *(const uint32_t *)(py + (size_t)(my * 16 - 4 + ((lane - 16) >> 2)) * ystride + mx * 16 + 4 * (lane & 3)) : 0u;
+                    if (lane < 16) T.y[(4 + lane) * 5] = ly;
+                    if (lane < 20) { /* lanes 0-15: the macroblock's rows; 16-19: the four rows above */
+                        const int r = lane < 16 ? lane : lane - 20; /* -4 .. 15 */
+                        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                        if (r >= 0 || aT) v = *(const uint4 *)(py + (size_t)(my * 16 + r) * ystride + mx * 16);
+                        uint32_t *d = &T.y[(4 + r) * 5 + 1];
+                        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+                    }
                 }
                 if (do_c) {
-                    if (lane < 32) { /* own: plane, row, dword */
-                        const int p = lane >> 4, r = (lane >> 1) & 7, d = lane & 1;
-                        T.c[p][(4 + r) * 3 + 1 + d] = *(const uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8 + 4 * d);
-                    } else if (lane < 48) { /* left: plane, row */
-                        const int p = (lane - 32) >> 3, r = lane & 7;
-                        T.c[p][(4 + r) * 3] = aL ? *(const uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8 - 4) : 0u;
-                    } else { /* top: plane, row, dword */
-                        const int p = (lane - 48) >> 3, r = (lane >> 1) & 3, d = lane & 1;
-                        T.c[p][r * 3 + 1 + d] = aT ? *(const uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 - 4 + r) * cstride + mx * 8 + 4 * d) : 0u;
+                    if (lane < 16) T.c[lane >> 3][(4 + (lane & 7)) * 3] = lc;
+                    if (lane < 24) { /* lanes 0-15: (plane, row); 16-23: (plane, row above) */
+                        const int p = lane < 16 ? lane >> 3 : (lane - 16) >> 2, r = lane < 16 ? (lane & 7) : ((lane - 16) & 3) - 4;
+                        uint2 v = make_uint2(0u, 0u);
+                        if (r >= 0 || aT) v = *(const uint2 *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8);
+                        uint32_t *d = &T.c[p][(4 + r) * 3 + 1];
+                        d[0] = v.x, d[1] = v.y;
                     }
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -161,48 +197,53 @@ __global__ __launch_bounds__(64 * DBK_MAX_WAVES) void k_deblock(venc_geom g, ven
                         int stride, pos; /* tile row stride in bytes, position of the edge inside the tile */
                         if (chroma) base = (uint8_t *)T.c[(lane >> 3) & 1], stride = 12, pos = 4 + 2 * e;
                         else base = (uint8_t *)T.y, stride = 20, pos = 4 + 4 * e;
-                        int s[8];
+                        int sm[8];
                         if (dir == 0) {
                             uint8_t *row = base + (4 + k) * stride + pos - 4;
 #pragma unroll
-                            for (int i = 0; i < 8; i++) s[i] = row[i];
-                            dbk_line(s, lbs, alpha, beta, (int)((tcw >> (8 * max(lbs - 1, 0))) & 255u), chroma);
+                            for (int i2 = 0; i2 < 8; i2++) sm[i2] = row[i2];
+                            dbk_line(sm, lbs, alpha, beta, (int)((tcw >> (8 * max(lbs - 1, 0))) & 255u), chroma);
 #pragma unroll
-                            for (int i = 1; i < 7; i++) row[i] = (uint8_t)s[i];
+                            for (int i2 = 1; i2 < 7; i2++) row[i2] = (uint8_t)sm[i2];
                         } else {
                             uint8_t *col = base + (pos - 4) * stride + 4 + k;
 #pragma unroll
-                            for (int i = 0; i < 8; i++) s[i] = col[i * stride];
-                            dbk_line(s, lbs, alpha, beta, (int)((tcw >> (8 * max(lbs - 1, 0))) & 255u), chroma);
+                            for (int i2 = 0; i2 < 8; i2++) sm[i2] = col[i2 * stride];
+                            dbk_line(sm, lbs, alpha, beta, (int)((tcw >> (8 * max(lbs - 1, 0))) & 255u), chroma);
 #pragma unroll
-                            for (int i = 1; i < 7; i++) col[i * stride] = (uint8_t)s[i];
+                            for (int i2 = 1; i2 < 7; i2++) col[i2 * stride] = (uint8_t)sm[i2];
                         }
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
                 }
-                /* ---- store: the macroblock, the columns left of it, the rows above it ---- */
+                /* ---- store: the macroblock and the rows above it as loaded; the columns left of it when its left edge was filtered ---- */
+                const bool vleft = aL && T.bs[0] != 0u, htop = aT && T.bs[4] != 0u; /* (wave-uniform: LDS words) */
                 if (do_y) {
-                    *(uint32_t *)(py + (size_t)(my * 16 + (lane >> 2)) * ystride + mx * 16 + 4 * (lane & 3)) = T.y[(4 + (lane >> 2)) * 5 + 1 + (lane & 3)];
-                    if (lane < 16) {
-                        if (aL) *(uint32_t *)(py + (size_t)(my * 16 + lane) * ystride + mx * 16 - 4) = T.y[(4 + lane) * 5];
-                    } else if (lane < 32) {
-                        if (aT) *(uint32_t *)(py + (size_t)(my * 16 - 4 + ((lane - 16) >> 2)) * ystride + mx * 16 + 4 * (lane & 3)) = T.y[((lane - 16) >> 2) * 5 + 1 + (lane & 3)];
+                    if (lane < 20) {
+                        const int r = lane < 16 ? lane : lane - 20;
+                        if (r >= 0 || htop) {
+                            const uint32_t *d = &T.y[(4 + r) * 5 + 1];
+                            *(uint4 *)(py + (size_t)(my * 16 + r) * ystride + mx * 16) = make_uint4(d[0], d[1], d[2], d[3]);
+                        }
                     }
+                    if (vleft && lane >= 32 && lane < 48) *(uint32_t *)(py + (size_t)(my * 16 + lane - 32) * ystride + mx * 16 - 4) = T.y[(4 + lane - 32) * 5];
                 }
                 if (do_c) {
-                    if (lane < 32) {
-                        const int p = lane >> 4, r = (lane >> 1) & 7, d = lane & 1;
-                        *(uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8 + 4 * d) = T.c[p][(4 + r) * 3 + 1 + d];
-                    } else if (lane < 48) {
+                    if (lane < 24) {
+                        const int p = lane < 16 ? lane >> 3 : (lane - 16) >> 2, r = lane < 16 ? (lane & 7) : ((lane - 16) & 3) - 4;
+                        if (r >= 0 || htop) {
+                            const uint32_t *d = &T.c[p][(4 + r) * 3 + 1];
+                            *(uint2 *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8) = make_uint2(d[0], d[1]);
+                        }
+                    }
+                    if (vleft && lane >= 32 && lane < 48) {
                         const int p = (lane - 32) >> 3, r = lane & 7;
-                        if (aL) *(uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8 - 4) = T.c[p][(4 + r) * 3];
-                    } else {
-                        const int p = (lane - 48) >> 3, r = (lane >> 1) & 3, d = lane & 1;
-                        if (aT) *(uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 - 4 + r) * cstride + mx * 8 + 4 * d) = T.c[p][r * 3 + 1 + d];
+                        *(uint32_t *)((p ? pc1 : pc0) + (size_t)(my * 8 + r) * cstride + mx * 8 - 4) = T.c[p][(4 + r) * 3];
                     }
                 }
             }
+            left_in_tile = any;
             __threadfence_block(); /* the stores above before the flag below */
             if (lane == 0) ((volatile int *)s_prog)[rl] = mx + 1;
         }
