@@ -143,7 +143,10 @@ void *venc_stream_handle(venc_ctx *c); /* hipStream_t of the main kernel chain *
  * venc_band_exchange_rccl(ctx, n_items, halo_rows) is then called after every step that a P picture follows:
  * halo_rows = 16 sends the band's two 16-row halos to the two neighbours (grouped ncclSend / ncclRecv), halo_rows = 0
  * all-gathers whole bands; everything is enqueued on the main stream, nothing blocks.  A single process calls it for each
- * of its contexts between venc_rccl_group_begin() and venc_rccl_group_end().  venc_rccl_agree(ctx, flag) is a
+ * of its contexts between venc_rccl_group_begin() and venc_rccl_group_end(): inside that group RCCL only records the
+ * transfers, so each such call leaves the unpacking of the peers' rows pending and venc_rccl_group_end() enqueues it,
+ * behind the collective, on every context's main stream -- the next step may be launched once it has returned.
+ * venc_rccl_pending() = exchanges of the calling thread whose unpacking is still pending.  venc_rccl_agree(ctx, flag) is a
  * host-synchronous MAX of `flag` over the ranks (use it at the end of a pass: a rank that failed makes all ranks stop).
  * RCCL is loaded at run time (librccl.so.1; VENC_RCCL_LIB overrides): engines that never call these do not load it. */
 #define VENC_RCCL_ID_BYTES 128
@@ -157,7 +160,9 @@ int venc_rccl_group_begin(void);
 int venc_rccl_group_end(void);
 int venc_rccl_agree(venc_ctx *c, int local_flag);
 long long venc_rccl_exchanges(const venc_ctx *c);
+int venc_rccl_pending(void);
 void venc_rccl_always(venc_ctx *c, int on); /* tests: run the collective even in a world of one */
+void venc_rccl_poison(venc_ctx *c, int on); /* tests: fill the receive buffer with 0xA5 before every collective, so that rows unpacked too early show */
 
 /* Completion tracking: venc_mark() returns a ticket for everything issued so
  * far; venc_wait(ticket) blocks the host until that point.  The engine may defer

@@ -239,6 +239,7 @@ def test_c_level_rccl_single_process_init_all(venc, orc):
     assert H.venc_rccl_init_all(arr, 1) == 0, H.venc_last_error()
     assert H.venc_rccl_world(e.h) == 1 and e.band_rows(0, 4) == (0, 18)
     H.venc_rccl_always(e.h, 1)
+    H.venc_rccl_poison(e.h, 1)
     ref = orc.Encoder(w, h, qp=28, n_slices=4, keyint=n, threads=4)
     for t in range(n):
         f = venc.synth_frame(w, h, t, 3)
@@ -246,7 +247,10 @@ def test_c_level_rccl_single_process_init_all(venc, orc):
         e.encode_step([t & 1], [t & 1], t == 0, t & 15, [0])
         assert H.venc_rccl_group_begin() == 0
         assert H.venc_band_exchange_rccl(e.h, 1, 16) == 0, H.venc_last_error()
+        # inside the group RCCL has only recorded the transfer: the unpack half must wait for venc_rccl_group_end
+        assert H.venc_rccl_pending() == 1
         assert H.venc_rccl_group_end() == 0
+        assert H.venc_rccl_pending() == 0
         e.sync()
         want = [unescape(b) for (ty, _, b) in split_nals(ref.encode(*f).data) if ty in (1, 5)]
         assert e.get_slices(t & 1) == want, "frame %d" % t

@@ -175,6 +175,9 @@ def bind_hip(L):
         L.venc_rccl_exchanges.argtypes = [C.c_void_p]
         L.venc_rccl_always.restype = None
         L.venc_rccl_always.argtypes = [C.c_void_p, C.c_int]
+        L.venc_rccl_poison.restype = None
+        L.venc_rccl_poison.argtypes = [C.c_void_p, C.c_int]
+        L.venc_rccl_pending.argtypes = []
     return L
 
 

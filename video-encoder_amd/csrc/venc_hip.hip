@@ -159,7 +159,7 @@ struct venc_ctx {
                      search.  Env VENC_ME=pool|tile|plane|dense (VENC_ME_DENSE=1 = dense). */
     /* slice-parallel mode over RCCL (venc_rccl.hip) */
     ncclComm_t rc_comm;
-    int rc_world, rc_rank, rc_items, rc_halo, rc_always;
+    int rc_world, rc_rank, rc_items, rc_halo, rc_always, rc_poison;
     void *rc_send, *rc_recv; /* own chunk; one chunk per rank (all-gather layout) */
     size_t rc_item_stride;
     int *rc_flag;

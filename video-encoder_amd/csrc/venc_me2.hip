@@ -438,8 +438,11 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
      * reports in last derives the NEXT picture's QP from it (spec/CODEC.md section 1a: the one 64-bit division per picture
      * and item) and leaves it in the next step's slot of the QP ring, where that step's kernels find it. */
     if (RC) {
-        __syncthreads(); /* (waits for this block's outstanding memory operations, its atomic corrections among them: they are
-                            acknowledged by L2, where the sum lives, before the arrival below is issued) */
+        /* every thread's correction must have reached L2, where the sum lives, before this block reports in: the atomics
+         * above are fire-and-forget and a workgroup barrier alone does not wait for them (no vmcnt(0) at workgroup scope
+         * outside tgsplit mode); the agent-scope release does, and correction and arrival go to different L2 channels */
+        __threadfence();
+        __syncthreads();
         if (tid == 0) {
             if (atomicAdd(&B.fix_done[item], 1u) == reporting - 1u) {
                 B.fix_done[item] = 0u; /* for the next launch (same stream: ordered) */

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     }
     __syncthreads();
     if (S.me_stop == 5) {
-        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = (uint32_t)(s_best[hw] >> 11) << 5;
+        if (l32 == 0 && mb_valid) B.mvsad[mbidx] = (uint32_t)(s_best[hw] >> 22) << 16; /* zero vector: nothing downstream reads out of range */
         return;
     }
     /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves; survivor k of the tile is entry
@@ -491,6 +491,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
     }
     }
+    if (S.me_stop == 6) return; /* diagnostic: the search is complete, the transform not started */
     /* ---- P5: the luma transform of the tile's macroblocks, straight from the LDS copies the search used: current samples
      * from s_cur, prediction from the window at the winning displacement -> residual, 4x4 transform, quantisation,
      * dequantisation, inverse transform, reconstruction, levels (venc_inter2.hip luma_block_code).  16 macroblocks x 16

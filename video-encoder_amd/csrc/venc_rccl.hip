@@ -189,8 +189,32 @@ extern "C" int venc_rccl_init_all(venc_ctx **ctxs, int n) {
 extern "C" int venc_rccl_world(const venc_ctx *c) { return c && c->rc_comm ? c->rc_world : 0; }
 extern "C" int venc_rccl_rank(const venc_ctx *c) { return c && c->rc_comm ? c->rc_rank : -1; }
 
-/* one exchange of the reconstruction just written, on the main stream.  Single-process users (venc_rccl_init_all) call
- * it for every context between venc_rccl_group_begin / venc_rccl_group_end. */
+/* Single-process hosts (venc_rccl_init_all) bracket the per-context exchange calls of one picture with
+ * venc_rccl_group_begin / venc_rccl_group_end.  Inside that outer group RCCL only RECORDS the sends, receives and
+ * all-gathers; they reach the contexts' streams at the outermost ncclGroupEnd.  Unpacking the peers' chunks must follow
+ * them in stream order, so an exchange called inside the group leaves its import half pending and
+ * venc_rccl_group_end runs it after the group has been submitted (round 2 launched the unpack kernels at once: stream
+ * order was export, unpack of the PREVIOUS picture's chunks, collective).  The group is a per-thread notion in RCCL,
+ * and so is this list. */
+static thread_local int g_group_depth = 0;
+static thread_local struct { venc_ctx *c; int n_items, halo_rows; } g_pending[64];
+static thread_local int g_n_pending = 0;
+
+static int rccl_import_peers(venc_ctx *c, int n_items, int halo_rows) {
+    const size_t stride = c->rc_item_stride, rank_bytes = stride * (size_t)c->rc_items;
+    uint8_t *recv = (uint8_t *)c->rc_recv;
+    const int lo = c->rc_rank - 1, hi = c->rc_rank + 1;
+    HIP_OK(hipSetDevice(c->cfg.device));
+    for (int peer = 0; peer < c->rc_world; peer++) {
+        if (peer == c->rc_rank || (halo_rows > 0 && peer != lo && peer != hi)) continue;
+        int f, n;
+        rccl_band_of(c->g.n_slices, c->rc_world, peer, &f, &n);
+        if (venc_band_import(c, n_items, recv + (size_t)peer * rank_bytes, stride, f, n, halo_rows) < 0) return -1;
+    }
+    return 0;
+}
+
+/* one exchange of the reconstruction just written, on the main stream */
 extern "C" int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows) {
     if (!c || !c->rc_comm) {
         SET_ERR("venc_band_exchange_rccl: no communicator (venc_rccl_init_rank / venc_rccl_init_all first)");
@@ -202,6 +226,8 @@ extern "C" int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows) 
     const size_t stride = c->rc_item_stride, rank_bytes = stride * (size_t)c->rc_items;
     uint8_t *send = (uint8_t *)c->rc_send, *recv = (uint8_t *)c->rc_recv;
     if (venc_band_export(c, n_items, send, stride, halo_rows) < 0) return -1;
+    if (c->rc_poison) /* tests: a chunk consumed before its collective has run shows up in the reconstruction */
+        HIP_OK(hipMemsetAsync(recv, 0xA5, rank_bytes * (size_t)c->rc_world, c->stream));
     const int lo = c->rc_rank - 1, hi = c->rc_rank + 1;
     if (halo_rows > 0) {
         NCCL_OK(g_nccl.GroupStart());
@@ -215,27 +241,50 @@ extern "C" int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows) 
     } else {
         NCCL_OK(g_nccl.AllGather(send, recv, rank_bytes, ncclUint8, c->rc_comm, c->stream));
     }
-    for (int peer = 0; peer < c->rc_world; peer++) {
-        if (peer == c->rc_rank || (halo_rows > 0 && peer != lo && peer != hi)) continue;
-        int f, n;
-        rccl_band_of(c->g.n_slices, c->rc_world, peer, &f, &n);
-        if (venc_band_import(c, n_items, recv + (size_t)peer * rank_bytes, stride, f, n, halo_rows) < 0) return -1;
-    }
     c->rc_exchanges++;
-    return 0;
+    if (g_group_depth > 0) { /* the collective is only recorded so far: unpack at venc_rccl_group_end */
+        if (g_n_pending >= 64) {
+            SET_ERR("venc_band_exchange_rccl: more than 64 exchanges inside one venc_rccl_group_begin / _end");
+            return -1;
+        }
+        g_pending[g_n_pending].c = c;
+        g_pending[g_n_pending].n_items = n_items;
+        g_pending[g_n_pending].halo_rows = halo_rows;
+        g_n_pending++;
+        return 0;
+    }
+    return rccl_import_peers(c, n_items, halo_rows);
 }
 
-/* single-process multi-GPU hosts bracket the per-context exchange calls of one picture with these */
+/* single-process multi-GPU hosts bracket the per-context exchange calls of one picture with these; the peers' rows are
+ * in place on every context's main stream once venc_rccl_group_end has returned */
 extern "C" int venc_rccl_group_begin(void) {
     if (rccl_load() != 0) return -1;
     NCCL_OK(g_nccl.GroupStart());
+    g_group_depth++;
     return 0;
 }
 extern "C" int venc_rccl_group_end(void) {
     if (rccl_load() != 0) return -1;
-    NCCL_OK(g_nccl.GroupEnd());
-    return 0;
+    if (g_group_depth <= 0) {
+        SET_ERR("venc_rccl_group_end without venc_rccl_group_begin");
+        return -1;
+    }
+    const ncclResult_t r = g_nccl.GroupEnd();
+    if (--g_group_depth > 0 && r == ncclSuccess) return 0; /* an inner pair: nothing has been submitted yet */
+    const int n = g_n_pending;
+    g_n_pending = 0;
+    if (r != ncclSuccess) {
+        SET_ERR("ncclGroupEnd failed: %s", g_nccl.GetErrorString(r));
+        return -1;
+    }
+    int rc = 0;
+    for (int i = 0; i < n; i++)
+        if (rccl_import_peers(g_pending[i].c, g_pending[i].n_items, g_pending[i].halo_rows) != 0) rc = -1;
+    return rc;
 }
+
+extern "C" int venc_rccl_pending(void) { return g_n_pending; }
 
 extern "C" int venc_rccl_agree(venc_ctx *c, int local_flag) {
     if (!c || !c->rc_comm) {
@@ -256,6 +305,10 @@ extern "C" long long venc_rccl_exchanges(const venc_ctx *c) { return c ? c->rc_e
 /* tests: run export, the collective and the (empty) import loop even in a world of one */
 extern "C" void venc_rccl_always(venc_ctx *c, int on) {
     if (c) c->rc_always = on;
+}
+/* tests: fill the receive buffer with 0xA5 on the main stream before every collective */
+extern "C" void venc_rccl_poison(venc_ctx *c, int on) {
+    if (c) c->rc_poison = on;
 }
 
 static void rccl_release(venc_ctx *c) {
