@@ -29,6 +29,12 @@ encodes its own clip (independent streams / closed GOPs shard with no data-path
 collective -- SURVEY.md section 8e, BASELINE config 4); value = pixels of all
 ranks / max-over-ranks time; scaling = "weak".
 
+--gpus N > 1 without RANK / WORLD_SIZE in the environment: bench.py starts the N rank processes itself (before anything in
+the parent touches a GPU) and relays rank 0's line; it never reports n_gpus 1 for a --gpus N request.  An N > 1 streams
+run also carries "slices_2160p": BASELINE config 5 (strong scaling) measured by a second set of rank processes that every
+rank starts BEFORE it touches its GPU and waits for under a time limit -- a fault or hang of the RCCL exchange, which
+has never met a second rank on hardware, cannot take the config-4 number with it.
+
 --mode slices (BASELINE config 5, e.g. --workload 2160p): ONE stream, every picture cut into the
 same 8 slices whatever N is, rank r codes a contiguous band of slices and the ranks swap
 reconstructed rows once per picture; the bands' payloads are gathered on rank 0 and
@@ -160,6 +166,121 @@ def pcie_inclusive(venc, torch, wl, clip, fb, gop_batch, device, passes=3):
         H.venc_host_free(hp)
 
 
+
+# ----------------------------------------------------------------------------- launching ranks
+ELASTIC_VARS = ("TORCHELASTIC_USE_AGENT_STORE", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS",
+                "TORCHELASTIC_ERROR_FILE", "TORCH_NCCL_ASYNC_ERROR_HANDLING", "GROUP_RANK", "ROLE_RANK", "ROLE_NAME", "ROLE_WORLD_SIZE",
+                "GROUP_WORLD_SIZE", "LOCAL_WORLD_SIZE")
+
+
+def rank_env(rank, world, port, base=None):
+    """Environment of one rank process started by bench.py itself (env:// rendezvous on 127.0.0.1, rank 0 hosts the store)."""
+    env = dict(base if base is not None else os.environ)
+    for k in ELASTIC_VARS:
+        env.pop(k, None)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def self_launch(argv, world):
+    """--gpus N > 1 and no WORLD_SIZE: the parent starts N rank processes of this script and touches no GPU itself.
+    Rank 0 inherits stdout (its one JSON line is this command's output); returns the worst exit code."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", 29500 + os.getpid() % 2000))
+    procs = []
+    for r in range(world):
+        env = rank_env(r, world, port)
+        env["BENCH_LAUNCHED_BY"] = "bench.py self-launch"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        pr.wait()
+        rc = rc or pr.returncode
+    if rc:
+        sys.stderr.write("bench: a rank process failed (exit code %d)\n" % rc)
+    return 1 if rc else 0
+
+
+def slices_leg(args, rank, world):
+    """BASELINE config 5 beside an N > 1 streams run: every rank starts ONE child (this script, --mode slices --workload
+    2160p, control plane on gloo so that the engine's RCCL is the only RCCL that makes a communicator there) before it has
+    touched its GPU, and waits for it under a time limit.  The children rendezvous among themselves on their own port.
+    Rank 0 returns the child's JSON line as a dict (or {"error": ...}); the other ranks return None."""
+    import signal
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29500")) + 23
+    env = rank_env(rank, world, port)
+    env["LOCAL_RANK"] = os.environ.get("LOCAL_RANK", str(rank))
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--mode", "slices", "--workload", "2160p", "--leg-child",
+           "--steps", str(args.slices_steps), "--warmup", "1", "--cpu-frames", "0", "--no-extras", "--halo", str(args.halo),
+           "--backend", args.backend, "--control", "gloo", "--gop-batch", str(args.gop_batch)]
+    if args.device >= 0:
+        cmd += ["--device", str(args.device)]
+    if args.dry_run:
+        cmd += ["--dry-run"]
+    t0 = time.perf_counter()
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL,
+                          stderr=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, start_new_session=True)
+    try:
+        out, err = pr.communicate(timeout=args.slices_timeout)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(pr.pid, signal.SIGKILL)  # its own session: nothing of ours is in that group
+        except OSError:
+            pass
+        pr.wait()
+        return {"error": "the slices leg did not finish within %d s and was stopped" % args.slices_timeout} if rank == 0 else None
+    if rank != 0:
+        return None
+    lines = [ln for ln in (out or b"").decode(errors="replace").splitlines() if ln.startswith("{")]
+    if pr.returncode != 0 or not lines:
+        return {"error": "the slices leg failed (exit code %s): %s" % (pr.returncode, (err or b"").decode(errors="replace")[-400:])}
+    d = json.loads(lines[-1])
+    d["leg_wall_s"] = round(time.perf_counter() - t0, 1)
+    return d
+
+
+class quiet_stdout:
+    """stdout carries ONE JSON line: whatever a library prints there while the process group forms (gloo announces its
+    connections on std::cout) goes to stderr instead."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def dry_run(args, rank, world, slices):
+    """CPU rehearsal of the launch logic (tests/test_dist.py): rendezvous, barrier, max-over-ranks, one JSON line.  No GPU."""
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        with quiet_stdout():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        t = torch.tensor([1.0 + rank], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == float(world)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        out = {"metric": "Mpixels/s encoded at fixed QP, 1080p & 4K YUV420p; bit-exact vs CPU ref", "value": 0.0, "unit": "Mpixels/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "mode": args.mode,
+               "launched_by": os.environ.get("BENCH_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "environment")}
+        if slices is not None:
+            out["slices_2160p"] = slices
+        print(json.dumps(out), flush=True)
+
+
 def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_rank, want_digest_frames=0):
     """One workload on this rank: the timed region of the contract + the untimed per-kernel passes.  Returns the fields
     of the JSON line that depend on the workload (rank 0) or None."""
@@ -245,6 +366,16 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             tally = one_pass()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    spread = None
+    if pipelined and tally is not None and int(tally.passes) >= 3:
+        # the K passes are ONE pipelined stream: a pass "ends" when its last frame reaches the sink (CLOCK_MONOTONIC stamps
+        # taken by the C tally sink); the first interval contains the pipeline's fill and is left out of the spread
+        ends = [int(tally.pass_end_ns[i]) for i in range(int(tally.passes))]
+        per = sorted((b - a) * 1e-9 for a, b in zip(ends[:-1], ends[1:]))
+        rate = lambda sec: round(frames * w * h / sec / 1e6, 1)
+        spread = {"passes": len(per), "min": rate(per[-1]), "median": rate(per[len(per) // 2]), "max": rate(per[0]), "unit": "Mpixels/s",
+                  "what": "rate of each timed pass but the first, from the delivery time of its last frame to the sink (one pipelined stream: "
+                          "neighbouring passes overlap, so single passes can read above the whole-run value)"}
     bytes_per_step = int(tally.bytes) // (steps if pipelined else 1) if tally else None
     bytes_timed = int(tally.bytes) if tally else None
     prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
@@ -278,7 +409,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
         digest = hip_digest(enc, clip.data_ptr(), fb, frames, want_digest_frames)
         host = clip[:want_digest_frames * fb].cpu().numpy().reshape(want_digest_frames, fb)  # the oracle's input: the very same bytes
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.control == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -288,7 +419,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
         res = {
             "value": round(px / dt / 1e6, 2),
             "ms_per_step": round(dt / steps * 1e3, 3),
-            "steps": steps, "warmup": warmup,
+            "steps": steps, "warmup": warmup, "per_pass": spread,
             "config": {"workload": wl["name"], "frames_per_step": frames, "gop_batch": gop_batch,
                        "parallelism": ("%d slice bands of one stream, %s exchange of reconstructed rows per picture (%s)" % (
                            world, "halo (%d luma rows per edge)" % args.halo if args.halo else "whole-band", args.backend))
@@ -306,6 +437,9 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             res["config"]["exchange"] = "C, RCCL (venc_band_exchange_rccl)" if c_exchange else "Python, torch.distributed %s (rehearsal)" % args.backend
             n_x = venc.hip_lib().venc_rccl_exchanges(eng) if c_exchange else xc.exchanges
             res["config"]["exchanges_per_step"] = int(n_x) // max(1, steps + warmup)
+            res["config"]["exchanges_per_picture"] = round(res["config"]["exchanges_per_step"] / float(frames), 4)
+            if c_exchange:
+                res["config"]["rccl_ranks"] = int(venc.hip_lib().venc_rccl_comm_count(eng))  # ncclCommCount of the engine's communicator
             if world > 1:
                 whole = stream_info.get("frames", [])
                 res["config"]["bytes_per_step"] = sum(len(f) for f in whole)
@@ -365,6 +499,16 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             if prof_iso:
                 res["kernel_ms_per_step_isolated"] = {k: round(v[0], 3) for k, v in prof_iso.items()}
     enc.close()
+    if slices_mode and world > 1 and args.leg_child:
+        # the same clip through ONE whole-picture encoder on rank 0 (untimed): the slice-parallel bitstream must equal it
+        if rank == 0:
+            solo = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1), gop_batch=gop_batch,
+                                    device=local_rank, intra_modes=args.intra_modes, crf=args.crf, subpel=args.subpel, deblock=args.deblock)
+            sha1, nb1 = hip_digest(solo, clip.data_ptr(), fb, frames, frames)
+            solo.close()
+            res["config"]["one_rank_sha256"] = sha1
+            res["config"]["equals_one_rank_bitstream"] = sha1 == res["config"].get("bitstream_sha256") and nb1 == res["config"].get("bytes_per_step")
+        barrier()
     extras = {}
     if rank == 0 and world == 1 and not slices_mode and args.pcie and wl_key == args.workload:
         extras["pcie_inclusive"] = pcie_inclusive(venc, torch, wl, clip, fb, gop_batch, local_rank)
@@ -393,25 +537,45 @@ def main():
     ap.add_argument("--intra-modes", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2], help="Intra16x16 prediction of I pictures: 0 DC only (default, the definition the metric's digests are frozen on), 1 vertical / horizontal / DC by SAD, 2 plane as well; not a headline configuration")
     ap.add_argument("--crf", type=float, default=None, help="X264_RC_CRF with this rate factor instead of fixed QP (spec/CODEC.md section 1a); not a headline configuration")
     ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
+    ap.add_argument("--control", default=None, choices=("nccl", "gloo"), help="torch.distributed backend of the control plane (barrier, max-over-ranks time, the RCCL id); default: --backend")
+    ap.add_argument("--no-slices-leg", action="store_true", help="N > 1 streams run: do not measure BASELINE config 5 beside it")
+    ap.add_argument("--slices-timeout", type=int, default=420, help="seconds the slices leg of an N > 1 run may take before it is stopped and reported as an error")
+    ap.add_argument("--slices-steps", type=int, default=3, help="timed passes of the slices leg")
+    ap.add_argument("--leg-child", action="store_true", help=argparse.SUPPRESS)  # this process is a rank of the slices leg started by slices_leg()
+    ap.add_argument("--dry-run", action="store_true", help="launch logic only (rendezvous, barrier, one JSON line): no GPU, gloo; the CPU test of --gpus N")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: start the N ranks here, before anything touches a GPU
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    args.control = args.control or ("gloo" if args.dry_run else args.backend)
+    slices = None
+    if world > 1 and args.mode == "streams" and not args.no_slices_leg and not args.leg_child:
+        slices = slices_leg(args, rank, world)  # before this process has touched its GPU
+    if args.dry_run:
+        return dry_run(args, rank, world, slices)
+
+    import torch
     if args.device >= 0:
         local_rank = args.device
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench: rank %d wants GPU %d, this node has %d" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+        with quiet_stdout():
+            if args.control == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(args.control, rank=rank, world_size=world)
+                dist.barrier()
 
     venc = importlib.import_module("video-encoder_amd")
     ORACLE_OPTS.update(crf=args.crf, intra_modes=args.intra_modes, subpel=args.subpel, deblock=args.deblock)
@@ -441,10 +605,25 @@ def main():
             "data": "synthetic",
             "config": res["config"],
         }
-        for k in ("roofline", "kernel_ms_per_step", "kernel_ms_per_step_isolated"):
-            if k in res:
+        for k in ("per_pass", "roofline", "kernel_ms_per_step", "kernel_ms_per_step_isolated"):
+            if res.get(k) is not None:
                 out[k] = res[k]
         out.update(extras)
+        if world > 1:
+            out["config"]["ranks_started_by"] = os.environ.get("BENCH_LAUNCHED_BY", "torchrun" if "TORCHELASTIC_RUN_ID" in os.environ else "environment")
+        if slices is not None:
+            # BASELINE config 5 beside the config-4 number: one 2160p stream in 8 slices, slice bands across the same N GPUs
+            if "error" in slices:
+                out["slices_2160p"] = slices
+            else:
+                c5 = slices.get("config", {})
+                out["slices_2160p"] = {"value": slices.get("value"), "unit": "Mpixels/s", "ms_per_step": slices.get("ms_per_step"), "steps": slices.get("steps"),
+                                       "n_gpus": slices.get("n_gpus"), "scaling": "strong", "parallelism": c5.get("parallelism"), "exchange": c5.get("exchange"),
+                                       "exchanges_per_step": c5.get("exchanges_per_step"), "exchanges_per_picture": c5.get("exchanges_per_picture"),
+                                       "rccl_ranks": c5.get("rccl_ranks"), "bitstream_sha256": c5.get("bitstream_sha256"),
+                                       "one_rank_sha256": c5.get("one_rank_sha256"), "equals_one_rank_bitstream": c5.get("equals_one_rank_bitstream"),
+                                       "leg_wall_s": slices.get("leg_wall_s"), "roofline": slices.get("roofline"),
+                                       "note": "measured by a second set of rank processes before the streams run (bench.py slices_leg); control plane gloo, data path RCCL inside the engine"}
     bit_exact = {}
     if extras_on:
         # BASELINE config 3 in the same invocation: the metric names both sizes.  Fewer steps (a pass is ~4x longer).

@@ -155,6 +155,7 @@ int venc_rccl_init_rank(venc_ctx *c, const uint8_t id[VENC_RCCL_ID_BYTES], int w
 int venc_rccl_init_all(venc_ctx **ctxs, int n);
 int venc_rccl_world(const venc_ctx *c);
 int venc_rccl_rank(const venc_ctx *c);
+int venc_rccl_comm_count(const venc_ctx *c); /* ncclCommCount of the context's communicator (0: none) */
 int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows);
 int venc_rccl_group_begin(void);
 int venc_rccl_group_end(void);

@@ -173,9 +173,14 @@ int x264_venc_encode_resident(x264_t *h, const void *d_frames, uint64_t frame_st
 int x264_venc_encode_resident_loop(x264_t *h, const void *d_frames, uint64_t frame_stride, int clip_frames, int repeats,
                                    int64_t first_pts, x264_venc_sink sink, void *user);
 
-/* ready-made sink: frame/byte counters + FNV-1a digest of every payload byte */
+/* ready-made sink: frame/byte counters + FNV-1a digest of every payload byte.  pass_frames != 0: the time
+ * (CLOCK_MONOTONIC, ns) at which the last frame of every pass_frames frames was delivered, for the first
+ * X264_VENC_TALLY_PASSES passes -- how a benchmark reads the spread between the passes of ONE pipelined stream */
+#define X264_VENC_TALLY_PASSES 256
 typedef struct {
     uint64_t frames, bytes, keyframes, fnv1a;
+    uint64_t pass_frames, passes;
+    uint64_t pass_end_ns[X264_VENC_TALLY_PASSES];
 } x264_venc_tally;
 int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int payload_bytes, const x264_picture_t *pic_out);
 /* the venc_ctx* behind an encoder (for venc_profile / venc_debug_read) */

@@ -218,3 +218,45 @@ def test_bitstreams_are_gathered_on_rank_zero_only():
         p.join(60)
         assert p.exitcode == 0
     assert whole == [b"".join(bytes([r, t]) * (3 + r) for r in range(3)) for t in range(5)]
+
+
+# ----------------------------------------------------------------------------- bench.py starts its own ranks
+def _bench_json(cmd, timeout=240):
+    import json
+    import subprocess
+    r = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # the contract: ONE line on stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_self_launches_its_ranks_and_reports_their_number():
+    """`python bench.py --gpus 2` with no RANK / WORLD_SIZE in the environment starts two rank processes itself (the parent
+    touches no GPU) and the one JSON line says n_gpus 2 -- never 1; the BASELINE config-5 leg (a second set of rank processes
+    with a rendezvous of their own) lands in the same line.  --dry-run: launch logic only, gloo, no GPU."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    os.environ.clear()
+    os.environ.update(env_clean)
+    d = _bench_json([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["dry_run"] is True and d["launched_by"] == "bench.py self-launch"
+    leg = d["slices_2160p"]
+    assert leg["n_gpus"] == 2 and leg["mode"] == "slices" and "error" not in leg
+
+
+@pytest.mark.timeout(300)
+def test_bench_under_torchrun_reports_the_world_size_and_runs_the_slices_leg():
+    """The driver's own command line: torchrun starts the ranks; the slices leg's children must not land on the agent's store."""
+    port = 29700 + os.getpid() % 200
+    d = _bench_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(port), "bench.py", "--gpus", "2", "--dry-run"])
+    assert d["n_gpus"] == 2 and d["launched_by"] == "torchrun"
+    assert d["slices_2160p"]["n_gpus"] == 2 and "error" not in d["slices_2160p"]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode != 0 and b"WORLD_SIZE 1 != --gpus 4" in r.stderr and not r.stdout.strip()

@@ -107,7 +107,8 @@ X264_RC_CQP, X264_RC_CRF = 0, 1
 NAL_SLICE, NAL_SLICE_IDR, NAL_SPS, NAL_PPS, NAL_FILLER = 1, 5, 7, 8, 12
 
 class X264Tally(C.Structure):
-    _fields_ = [("frames", C.c_uint64), ("bytes", C.c_uint64), ("keyframes", C.c_uint64), ("fnv1a", C.c_uint64)]
+    _fields_ = [("frames", C.c_uint64), ("bytes", C.c_uint64), ("keyframes", C.c_uint64), ("fnv1a", C.c_uint64),
+                ("pass_frames", C.c_uint64), ("passes", C.c_uint64), ("pass_end_ns", C.c_uint64 * 256)]
 
 
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(X264Nal), C.c_int, C.c_int, C.POINTER(X264Picture))
@@ -178,6 +179,7 @@ def bind_hip(L):
         L.venc_rccl_poison.restype = None
         L.venc_rccl_poison.argtypes = [C.c_void_p, C.c_int]
         L.venc_rccl_pending.argtypes = []
+        L.venc_rccl_comm_count.argtypes = [C.c_void_p]
     return L
 
 
@@ -616,6 +618,7 @@ class X264Encoder:
         """Same, with the C tally sink (no Python in the loop): returns X264Tally.  repeats > 1: that many passes of
         the resident clip as one stream (x264_venc_encode_resident_loop): consecutive passes overlap."""
         t = X264Tally()
+        t.pass_frames = n_frames  # CLOCK_MONOTONIC stamps at the end of every pass (x264_venc_tally.pass_end_ns)
         fn = C.cast(self.L.x264_venc_tally_sink, C.c_void_p)
         r = self.L.x264_venc_encode_resident_loop(self.h, C.c_void_p(dev_ptr), frame_stride, n_frames, repeats, first_pts, fn,
                                                   C.cast(C.pointer(t), C.c_void_p))

@@ -32,6 +32,7 @@ struct venc_rccl_api {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int);
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *);
     ncclResult_t (*CommDestroy)(ncclComm_t);
+    ncclResult_t (*CommCount)(const ncclComm_t, int *);
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t);
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
@@ -65,6 +66,7 @@ static int rccl_load(void) {
     RCCL_SYM(CommInitRank, "ncclCommInitRank");
     RCCL_SYM(CommInitAll, "ncclCommInitAll");
     RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    RCCL_SYM(CommCount, "ncclCommCount");
     RCCL_SYM(Send, "ncclSend");
     RCCL_SYM(Recv, "ncclRecv");
     RCCL_SYM(AllGather, "ncclAllGather");
@@ -186,6 +188,14 @@ extern "C" int venc_rccl_init_all(venc_ctx **ctxs, int n) {
     return 0;
 }
 
+/* the communicator's own count of its ranks (ncclCommCount): what a benchmark quotes as evidence that the exchange ran
+ * on a world of that size */
+extern "C" int venc_rccl_comm_count(const venc_ctx *c) {
+    if (!c || !c->rc_comm) return 0;
+    int n = 0;
+    NCCL_OK(g_nccl.CommCount(c->rc_comm, &n));
+    return n;
+}
 extern "C" int venc_rccl_world(const venc_ctx *c) { return c && c->rc_comm ? c->rc_world : 0; }
 extern "C" int venc_rccl_rank(const venc_ctx *c) { return c && c->rc_comm ? c->rc_rank : -1; }
 

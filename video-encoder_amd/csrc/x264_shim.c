@@ -651,6 +651,11 @@ int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int 
     t->frames++;
     t->bytes += (uint64_t)payload_bytes;
     t->keyframes += (uint64_t)(pic_out && pic_out->b_keyframe);
+    if (t->pass_frames && t->frames % t->pass_frames == 0 && t->passes < X264_VENC_TALLY_PASSES) {
+        struct timespec ts;
+        clock_gettime(CLOCK_MONOTONIC, &ts);
+        t->pass_end_ns[t->passes++] = (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+    }
     return 0;
 }
 
