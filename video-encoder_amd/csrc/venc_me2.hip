@@ -317,6 +317,9 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     __shared__ int s_mv[2];
     const int item = blockIdx.z, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    /* the block's first list entry is fetched together with the count (it is meaningful only below the count): one memory
+     * round trip less on a kernel whose whole cost is latency */
+    const uint32_t first_mb = B.fix_list[(size_t)item * g.nmb + min((int)blockIdx.x, g.nmb - 1)];
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
     /* blocks with a listed macroblock (under rate control: block 0 too when nothing is listed: somebody has to close the sum) */
     const uint32_t reporting = RC ? max(1u, min(count, (uint32_t)gridDim.x)) : count;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
 #pragma unroll
     for (int k = 0; k < FIX_NDY; k++) rk[k] = (blockIdx.x < count && dy0 + k <= 32 && lane < 33) ? (uint32_t)B.me_rank[(dy0 + k) * 33 + dxi] : 0x7ffu;
     for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const int mb = (int)B.fix_list[(size_t)item * g.nmb + i];
+        const int mb = (int)(i == blockIdx.x ? first_mb : B.fix_list[(size_t)item * g.nmb + i]);
         const int mx = mb % g.mbw, my = mb / g.mbw;
         const int x0 = mx * 16, y0 = my * 16;
         __syncthreads();

@@ -168,10 +168,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
     }
     {
-        const uint4 va = me3_window_piece(ref, rstride, g, x0, y0, tid);
         const int ra = tid / 10, qa = tid - ra * 10;
         uint32_t *da = s_win + ra * T2_WD + 4 * qa;
-        *(uint2 *)da = make_uint2(va.x, va.y); /* row stride is 8-byte aligned only */
+        /* a tile whose window lies inside the coded picture (all but the rim: 87 % of the tiles at 1080p) needs neither clamps
+         * nor edge replication: one address, one load per piece */
+        const bool interior = x0 >= 16 && x0 + 144 <= g.cw && y0 >= 16 && y0 + 48 <= g.ch; /* block-uniform */
+        if (interior) {
+            const uint8_t *w0 = ref + (size_t)(y0 - 16) * rstride + (x0 - 16);
+            const uint4 va = *(const uint4 *)(w0 + ra * rstride + 16 * qa);
+            uint4 vb = make_uint4(0u, 0u, 0u, 0u);
+            const bool second = tid + 512 < T2_WR * 10;
+            const int i1 = tid + 512, rb = i1 / 10, qb = i1 - rb * 10;
+            if (second) vb = *(const uint4 *)(w0 + rb * rstride + 16 * qb);
+            *(uint2 *)da = make_uint2(va.x, va.y); /* row stride is 8-byte aligned only */
+            *(uint2 *)(da + 2) = make_uint2(va.z, va.w);
+            if (second) {
+                uint32_t *db = s_win + rb * T2_WD + 4 * qb;
+                *(uint2 *)db = make_uint2(vb.x, vb.y);
+                *(uint2 *)(db + 2) = make_uint2(vb.z, vb.w);
+            }
+        } else {
+        const uint4 va = me3_window_piece(ref, rstride, g, x0, y0, tid);
+        *(uint2 *)da = make_uint2(va.x, va.y);
         *(uint2 *)(da + 2) = make_uint2(va.z, va.w);
         if (tid + 512 < T2_WR * 10) {
             const int i1 = tid + 512, rb = i1 / 10, qb = i1 - rb * 10;
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             uint32_t *db = s_win + rb * T2_WD + 4 * qb;
             *(uint2 *)db = make_uint2(vb.x, vb.y);
             *(uint2 *)(db + 2) = make_uint2(vb.z, vb.w);
+        }
         }
         if (tid < T2_WR) {
             s_win[tid * T2_WD + 40] = 0;
@@ -287,7 +306,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const unsigned long long kp = ((unsigned long long)((sad_p << 11) | rank_p) << 11) | (uint32_t)ci_p;
             const unsigned long long kz = ((unsigned long long)((sad_z << 11) | rank_z) << 11) | (uint32_t)ci_z;
             s_best[hw] = kp < kz ? kp : kz;
-            s_ovf[hw] = 0;
         }
     }
     if (S.me_stop == 4) { /* diagnostic: start points done, bounds not started */
@@ -431,7 +449,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
                 }
             }
         }
-        if (l32 == 0 && mycnt > T3_CAP) s_ovf[hw] = 1;
+        if (l32 == 0) s_ovf[hw] = mycnt; /* > T3_CAP: the macroblock is left to k_me_fix */
         if (lane == 0) s_wcnt[tid >> 6] = wcnt;
     }
     __syncthreads();
@@ -461,7 +479,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const uint32_t e = found ? s_pool[sbase + (k - start)] : 0xffffffffu;
             const int ehw = (int)((e >> 11) & 15u), ci = (int)(e & 2047u);
             bool need = found;
-            if (need) need = s_ovf[ehw] == 0u && (e >> 15) <= (uint32_t)(s_best[ehw] >> 22);
+            if (need) need = s_ovf[ehw] <= (uint32_t)T3_CAP && (e >> 15) <= (uint32_t)(s_best[ehw] >> 22);
             if (__ballot(need) == 0ull) continue;
             const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
             const int ecol = need ? (ehw & (T2_MBX - 1)) * 16 : 0, erow = need ? (ehw >> 3) * 16 : 0;
@@ -471,25 +489,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         }
     }
     __syncthreads();
-    /* (indices once more from an opaque copy of the thread id: carried across the survivor scan and P4b, the 64-bit
-     * macroblock index was spilled to scratch -- 8 bytes per lane stored and reloaded by every wave) */
-    {
-    int tid_c = threadIdx.x;
-    asm volatile("" : "+v"(tid_c));
-    const int l32 = tid_c & 31, hw = tid_c >> 5;
-    const int mx = tx * T2_MBX + (hw & (T2_MBX - 1)), my = S.row0 + ty * T2_MBY + (hw >> 3);
-    const bool mb_valid = mx < g.mbw && my < S.row1;
-    const size_t mbidx = (size_t)item * g.nmb + (size_t)min(my, g.mbh - 1) * g.mbw + min(mx, g.mbw - 1);
-    if (l32 == 0 && mb_valid) {
-        const unsigned long long best = s_best[hw];
-        const uint32_t ci = (uint32_t)best & 2047u, bcy = ci / 33u;
-        const int dx = (int)(ci - bcy * 33u) - 16, dy = (int)bcy - 16;
-        B.mvsad[mbidx] = ((uint32_t)(best >> 22) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
-        const bool overflow = mycnt > T3_CAP;
-        B.me_flag[mbidx] = overflow ? 1 : 0; /* k_me_fix searches it exhaustively */
-        if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(my * g.mbw + mx);
-        B.me_cnt[mbidx] = (uint8_t)min(mycnt, 255u); /* introspection: survivors of the bound test besides the start points */
-    }
+    /* the tile's results go out from ONE wave (wave 6, which has nothing to do in P5; lane = macroblock): vectors, the list
+     * for k_me_fix, the survivor counts.  Every wave used to store its own two macroblocks' -- ~30 instructions per wave for
+     * two busy lanes. */
+    if ((threadIdx.x >> 6) == 6) {
+        const int m = (int)(threadIdx.x & 63u);
+        const int mx = tx * T2_MBX + (m & (T2_MBX - 1)), my = S.row0 + ty * T2_MBY + ((m >> 3) & (T2_MBY - 1));
+        if (m < T2_MBX * T2_MBY && mx < g.mbw && my < S.row1) {
+            const size_t mbidx = (size_t)item * g.nmb + (size_t)my * g.mbw + mx;
+            const unsigned long long best = s_best[m];
+            const uint32_t cnt = s_ovf[m];
+            const uint32_t ci = (uint32_t)best & 2047u, bcy = ci / 33u;
+            const int dx = (int)(ci - bcy * 33u) - 16, dy = (int)bcy - 16;
+            B.mvsad[mbidx] = ((uint32_t)(best >> 22) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+            const bool overflow = cnt > T3_CAP;
+            B.me_flag[mbidx] = overflow ? 1 : 0; /* k_me_fix searches it exhaustively */
+            if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(my * g.mbw + mx);
+            B.me_cnt[mbidx] = (uint8_t)min(cnt, 255u); /* introspection: survivors of the bound test besides the start points */
+        }
     }
     if (S.me_stop == 6) return; /* diagnostic: the search is complete, the transform not started */
     /* ---- P5: the luma transform of the tile's macroblocks, straight from the LDS copies the search used: current samples
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
          * launch is left on either stream. */
         const int t6 = threadIdx.x - 256, m = t6 >> 3;
         const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
-        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] == 0u;
+        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] <= (uint32_t)T3_CAP;
         const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
         inter_chroma_mb(g, B, S, item, t6 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, (int)bcx - 16, (int)bcy - 16, qc5);
     }
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         const int t5 = threadIdx.x, m = t5 >> 4, blk = t5 & 15;
         const int mcol0 = (m & (T2_MBX - 1)) * 16, mrow0 = (m >> 3) * 16;
         const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
-        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] == 0u;
+        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] <= (uint32_t)T3_CAP;
         const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
         const int bx = blk_x(blk) * 4, by = blk_y(blk) * 4;
         const int boff = mcol0 + (int)bcx + bx;
