@@ -79,21 +79,50 @@ def host_frames(wl, host):
 ORACLE_OPTS = {}  # the coding options of this run that are not part of the workload (--crf, --intra-modes, --subpel)
 
 
-def oracle_run(wl, clip, threads):
-    """The CPU oracle over `clip` (list of (y, u, v)): (seconds, sha256 of the concatenated payloads, bytes)."""
+def oracle_run(wl, clip, threads, gop_workers=1):
+    """The CPU oracle over `clip` (list of (y, u, v)): (seconds, sha256 of the concatenated payloads, bytes).
+    gop_workers > 1: closed GOPs are independent, so that many encoder instances (each slice-parallel on `threads` OpenMP
+    threads, its idr_base = the index of its GOP) work side by side from a thread pool (ctypes releases the GIL); their
+    streams concatenate, in GOP order, to exactly the one-encoder stream (tests/test_dist.py)."""
     import orc_py
     o = ORACLE_OPTS
-    enc = orc_py.Encoder(wl["w"], wl["h"], qp=int(round(o["crf"])) if o.get("crf") is not None else wl["qp"], n_slices=wl["slices"], keyint=wl["keyint"],
-                         fps=(30, 1), sar=(1, 1), threads=threads, rc=o.get("crf") is not None, intra_modes=int(o.get("intra_modes") or 0), subpel=int(o.get("subpel", 0)), deblock=bool(o.get("deblock")))
+    keyint = wl["keyint"]
+
+    def make(idr_base):
+        return orc_py.Encoder(wl["w"], wl["h"], qp=int(round(o["crf"])) if o.get("crf") is not None else wl["qp"], n_slices=wl["slices"], keyint=keyint,
+                              fps=(30, 1), sar=(1, 1), threads=threads, idr_base=idr_base, rc=o.get("crf") is not None,
+                              intra_modes=int(o.get("intra_modes") or 0), subpel=int(o.get("subpel", 0)), deblock=bool(o.get("deblock")))
+
+    def gop(gi):
+        enc = make(gi)
+        out = [enc.encode(y, u, v).data for y, u, v in clip[gi * keyint:(gi + 1) * keyint]]
+        enc.close()
+        return out
+    n_gops = (len(clip) + keyint - 1) // keyint
     md, nbytes = hashlib.sha256(), 0
     t0 = time.perf_counter()
-    for y, u, v in clip:
-        d = enc.encode(y, u, v).data
-        md.update(d)
-        nbytes += len(d)
+    if gop_workers > 1 and n_gops > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=gop_workers) as ex:
+            parts = list(ex.map(gop, range(n_gops)))
+    else:  # one encoder over the whole clip
+        enc = make(0)
+        parts = [[enc.encode(y, u, v).data for y, u, v in clip]]
+        enc.close()
     dt = time.perf_counter() - t0
-    enc.close()
+    for part in parts:
+        for d in part:
+            md.update(d)
+            nbytes += len(d)
     return dt, md.hexdigest(), nbytes
+
+
+def cpu_shape(n_gops):
+    """(threads per encoder, encoders side by side) for the all-cores CPU baseline: slices are the unit inside an encoder
+    (8 per picture), closed GOPs the unit across encoders."""
+    cores = os.cpu_count() or 1
+    threads = min(8, cores)
+    return threads, max(1, min(n_gops, cores // threads))
 
 
 def hip_digest(enc, clip_ptr, fb, frames, first):
@@ -458,16 +487,32 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                 algo_bytes = ME_ALGO_BYTES_PER_PX * px_per_launch
                 avg_s = me_ms / me_n * 1e-3
                 achieved = algo_bytes / avg_s / 1e9
-                traffic = None
-                tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(tfile):
+                # kept counter values (PMC passes cannot run inside this process): quoted only while the device sources are
+                # the ones they were collected on
+                traffic, traffic_source, valu = None, "no profiles/pmc_traffic.json", None
+                src_now = venc.kernel_sources_sha16()
+                for fname, key in (("pmc_traffic.json", "traffic"), ("sq_counters.json", "valu")):
+                    path = os.path.join(ROOT, "profiles", fname)
+                    if not os.path.exists(path):
+                        continue
                     try:
-                        traffic = json.load(open(tfile)).get(wl_key, {}).get("k_me_hbm_bytes_per_launch")
+                        doc = json.load(open(path))
                     except Exception:
-                        traffic = None
+                        continue
+                    tag = doc.get("source") or {}
+                    fresh = tag.get("kernel_sources_sha16") == src_now
+                    where = "profiles/%s collected %s at commit %s (kernel sources %s)" % (fname, tag.get("collected"), tag.get("git_head"), tag.get("kernel_sources_sha16"))
+                    if key == "traffic":
+                        traffic = doc.get(wl_key, {}).get("k_me_hbm_bytes_per_launch") if fresh else None
+                        traffic_source = where if fresh else "dropped: %s is older than the kernels now built (%s)" % (where, src_now)
+                    elif fresh and doc.get(wl_key, {}).get("k_me_pool"):
+                        kk = doc[wl_key]["k_me_pool"]
+                        valu = {"bound": "valu issue", "frac": kk.get("valu_issue_frac"), "valu_wave_instructions_per_launch": kk.get("valu_wave_instructions_per_launch"),
+                                "isolated_launch_us": kk.get("avg_us"), "lds_busy_frac": kk.get("lds_busy_frac"), "source": where,
+                                "note": "the bound that is active: SQ_INSTS_VALU x 4.3 cycles (tools/valu_ubench.hip) over the SIMD-cycles of an isolated launch"}
                 res["roofline"] = {"bound": "hbm", "kernel": "k_me_pool = exact +-16 full search + luma 4x4 transform / quantisation / reconstruction, fused (the ME+DCT kernel)",
                                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                                   "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                                    "algorithmic_bytes_per_launch": int(algo_bytes),
                                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": me_n, "launches_sampled_one_in": ME_EVENT_STRIDE,
                                    "search_positions_per_s": round(1089.0 * 256.0 * px_per_launch / 256.0 / avg_s, 1),
@@ -476,6 +521,8 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                                    "note": "HBM is the bound this line is priced against; the kernel itself is VALU/LDS bound (DESIGN.md 4.1). "
                                            "Algorithmic bytes = 2.0 B per P-frame pixel read (cur Y + ref Y); since round 2 the same launch also does the luma "
                                            "transform that round 1 ran as a separate kernel, so its duration is not comparable with round 1's search-only k_me_pool"}
+                if valu:
+                    res["roofline_valu"] = valu
                 # the whole P path of SURVEY.md section 8d (3.0 B/px read: cur Y+U+V 1.5, ref Y 1.0, ref U+V 0.5) over one main-chain period
                 if prof_all:
                     chain_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in ("k_me", "k_me_fix", "k_inter"))
@@ -605,7 +652,7 @@ def main():
             "data": "synthetic",
             "config": res["config"],
         }
-        for k in ("per_pass", "roofline", "kernel_ms_per_step", "kernel_ms_per_step_isolated"):
+        for k in ("per_pass", "roofline", "roofline_valu", "kernel_ms_per_step", "kernel_ms_per_step_isolated"):
             if res.get(k) is not None:
                 out[k] = res[k]
         out.update(extras)
@@ -628,30 +675,34 @@ def main():
     if extras_on:
         # BASELINE config 3 in the same invocation: the metric names both sizes.  Fewer steps (a pass is ~4x longer).
         args.pcie = False
-        r2, _, host2 = measure(args, torch, dist, venc, "2160p", max(3, args.steps // 2), 2, rank, world, local_rank,
-                               want_digest_frames=60 if check else 0)
-        out["2160p"] = {k: r2[k] for k in ("value", "ms_per_step", "steps", "warmup", "roofline", "kernel_ms_per_step", "config") if k in r2}
+        wl2 = WORKLOADS["2160p"]
+        n2 = min(args.cpu_frames, wl2["frames"]) if check else 0  # all 300 frames by default
+        r2, _, host2 = measure(args, torch, dist, venc, "2160p", max(3, args.steps // 2), 2, rank, world, local_rank, want_digest_frames=n2)
+        out["2160p"] = {k: r2[k] for k in ("value", "ms_per_step", "steps", "warmup", "per_pass", "roofline", "roofline_valu", "kernel_ms_per_step", "config") if r2.get(k) is not None}
         out["2160p"]["unit"] = "Mpixels/s"
         if check:
-            wl2 = WORKLOADS["2160p"]
-            dt2, sha2, nb2 = oracle_run(wl2, host_frames(wl2, host2), min(os.cpu_count() or 1, 16))
+            th2, gw2 = cpu_shape((n2 + wl2["keyint"] - 1) // wl2["keyint"])
+            dt2, sha2, nb2 = oracle_run(wl2, host_frames(wl2, host2), th2, gw2)
             del host2
-            bit_exact["2160p"] = {"frames": 60, "hip_sha256": r2.get("hip_sha256"), "oracle_sha256": sha2, "bytes": nb2,
-                                  "equal": r2.get("hip_sha256") == sha2 and r2.get("hip_sha256_bytes") == nb2}
+            bit_exact["2160p"] = {"frames": n2, "hip_sha256": r2.get("hip_sha256"), "oracle_sha256": sha2, "bytes": nb2,
+                                  "equal": r2.get("hip_sha256") == sha2 and r2.get("hip_sha256_bytes") == nb2,
+                                  "oracle_Mpx_s": round(n2 * wl2["w"] * wl2["h"] / dt2 / 1e6, 2), "oracle_threads": th2 * gw2}
     if check and rank == 0:
         # all-cores CPU baseline on a bounded sample of the same workload = the oracle side of the bit-exact check
         n = min(args.cpu_frames, wl["frames"])
-        threads = min(os.cpu_count() or 1, 16)
+        kf = (n + wl["keyint"] - 1) // wl["keyint"]
+        th, gw = cpu_shape(kf)
+        threads = th * gw
         clip_h = host_frames(wl, host)
-        dt_c, sha_c, nb_c = oracle_run(wl, clip_h, threads)
+        dt_c, sha_c, nb_c = oracle_run(wl, clip_h, th, gw)
         n1 = min(wl["keyint"], n)  # one-thread line: one closed GOP
         dt_1, _, _ = oracle_run(wl, clip_h[:n1], 1)
-        kf = (n + wl["keyint"] - 1) // wl["keyint"]
         out["cpu_baseline"] = {
             "value": round(n * wl["w"] * wl["h"] / dt_c / 1e6, 3), "unit": "Mpixels/s", "cores": threads, "host_cores": os.cpu_count(),
             "kind": "port",
-            "sample": "first %d frames (%d I + %d P, closed GOPs of %d) of the same %dx%d clip, %d OpenMP threads, %.1f s" % (
-                n, kf, n - kf, wl["keyint"], wl["w"], wl["h"], threads, dt_c),
+            "sample": "first %d frames (%d I + %d P, closed GOPs of %d) of the same %dx%d clip, %d encoders side by side (one per closed GOP) x %d OpenMP threads "
+                      "(one per slice) = %d threads: all the independence this stream has (%d GOPs x %d slices), %.1f s" % (
+                n, kf, n - kf, wl["keyint"], wl["w"], wl["h"], gw, th, threads, kf, wl["slices"], dt_c),
             "one_thread": {"value": round(n1 * wl["w"] * wl["h"] / dt_1 / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
                            "sample": "first %d frames (one closed GOP) of the same clip, 1 thread, %.1f s" % (n1, dt_1)},
             "note": ORACLE_NOTE}

@@ -20,10 +20,19 @@
  * i_dts, b_keyframe, img.plane[], img.i_stride[]} (:543-547, :775-783);
  * x264_nal_t {i_type, i_payload, p_payload} (:682, :703-705, :722).
  *
- * Documented deviations: the encoder is a fixed-QP
- * H.264 Constrained-Baseline subset; X264_RC_CRF maps f_rf_constant to
- * QP = round(f) clamped to 12..51; presets and tunes are accepted by name but
- * only "zerolatency" changes behaviour (no output delay).
+ * Documented deviations (spec/CODEC.md): the encoder is an
+ * H.264 Constrained-Baseline subset (CAVLC, one reference, no B pictures).
+ * X264_RC_CQP codes every picture at rc.i_qp_constant; X264_RC_CRF -- what the
+ * reference sets (av_encode.c:400-401) -- is a frame-level approximation decided
+ * on the GPU (spec/CODEC.md section 1a: IDR pictures at round(f) - 3, P pictures
+ * at round(f) +- up to 6 steered by the previous picture's SAD sum; base clamped
+ * to 12..51), not libx264's adaptive rate control.  Preset names select the
+ * optional coding tools as libx264's do in spirit: every preset but "ultrafast"
+ * switches on quarter-sample motion refinement (hip.i_subpel = 2), the in-loop
+ * deblocking filter (hip.i_deblock = 1) and Intra16x16 V / H / DC / plane
+ * prediction (hip.i_intra_modes = 2); "ultrafast" leaves them off.  Of the tunes
+ * only "zerolatency" changes behaviour (no output delay).  Unknown names fail
+ * (av_encode.c:384-386).
  */
 #ifndef X264_VENC_X264_H
 #define X264_VENC_X264_H

@@ -260,3 +260,23 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "4", "--dry-run"], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert r.returncode != 0 and b"WORLD_SIZE 1 != --gpus 4" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_gop_parallel_oracle_equals_the_single_encoder_stream():
+    """bench.py's all-cores CPU baseline runs one oracle encoder per closed GOP side by side: the digest over the GOP-ordered
+    concatenation must be the one-encoder digest (fixed QP and under rate control, whose state restarts with every GOP)."""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bench
+    from conftest import noise_frames
+    wl = dict(w=64, h=48, frames=14, keyint=4, qp=30, slices=2)
+    clip = noise_frames(64, 48, 14, seed=5)
+    for opts in (dict(), dict(crf=30.0)):
+        bench.ORACLE_OPTS.clear()
+        bench.ORACLE_OPTS.update(opts)
+        _, sha1, n1 = bench.oracle_run(wl, clip, 2, 1)
+        _, sha3, n3 = bench.oracle_run(wl, clip, 2, 3)
+        assert (sha1, n1) == (sha3, n3)
+    bench.ORACLE_OPTS.clear()
+    assert bench.cpu_shape(10)[0] * bench.cpu_shape(10)[1] <= max(8, os.cpu_count() or 1)

@@ -42,5 +42,13 @@ doc["note"] = ("HBM bytes per launch from rocprofv3 PMC passes (separate --pmc F
                "--steps 1 --warmup 0 --no-profile, 10 items per launch; tools/pmc_summary.py). FETCH_SIZE and WRITE_SIZE are in KiB; "
                "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B).")
 doc[sys.argv[3]] = out
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib, subprocess, time
+try:
+    head = subprocess.check_output(["git", "-C", os.path.dirname(path), "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+except Exception:
+    head = None  # (the GPU box's copy has no .git: tools/collect_profiles.py fills it in when the summary is kept)
+doc["source"] = {"kernel_sources_sha16": importlib.import_module("video-encoder_amd").kernel_sources_sha16(), "git_head": head,
+                 "collected": time.strftime("%Y-%m-%d"), "how": "tools/final_batch.sh -> tools/pmc_summary.py"}
 json.dump(doc, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

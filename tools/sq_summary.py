@@ -30,10 +30,30 @@ print("# valu_util = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration x 2.4 GHz
 names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES",
          "SQ_WAVE_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS"]
 print("%-14s %8s %9s %8s  " % ("kernel", "avg_us", "valu_util", "lds_busy") + " ".join("%20s" % n for n in names))
+VALU_ISSUE_CYCLES = 4.3  # measured cost of one wave-instruction on a SIMD with >= 2 waves (tools/valu_ubench.hip: 4.2-4.5 for all but four opcodes)
+doc_k = {}
 for k in ("k_me_pool", "k_me_fix", "k_inter_fused", "k_skip", "k_cavlc_p", "k_scan", "k_pack", "k_intra_fwd", "k_intra_dc", "k_intra_rec", "k_cavlc"):
     if not dur[k][1]:
         continue
     us = dur[k][0] / dur[k][1]
     v = lambda c: acc[k][c][0] / max(1, acc[k][c][1])
+    doc_k[k] = {"avg_us": round(us, 2), "valu_wave_instructions_per_launch": int(v("SQ_INSTS_VALU")),
+                "valu_issue_frac": round(v("SQ_INSTS_VALU") * VALU_ISSUE_CYCLES / (1024 * us * 2400), 4),
+                "lds_busy_frac": round(v("SQ_LDS_IDX_ACTIVE") / (256 * us * 2400), 4)}
     print("%-14s %8.1f %8.1f%% %7.1f%%  " % (k, us, 100 * v("SQ_INSTS_VALU") * 4 / (1024 * us * 2400), 100 * v("SQ_LDS_IDX_ACTIVE") / (256 * us * 2400)) +
           " ".join("%20.0f" % v(n) for n in names))
+
+if len(sys.argv) > 3:  # sq_summary.py <dir> <label> <profiles/sq_counters.json>: keep the utilisation figures bench.py quotes
+    import importlib
+    import json
+    import os
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    path = sys.argv[3]
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc["note"] = ("per launch, every kernel alone on the chip (VENC_NO_OVERLAP=1), 10 items per launch; valu_issue_frac = SQ_INSTS_VALU x %.1f cycles "
+                   "(measured issue cost of a wave-instruction, tools/valu_ubench.hip) / (1024 SIMDs x duration x 2.4 GHz)" % VALU_ISSUE_CYCLES)
+    doc[label] = doc_k
+    doc["source"] = {"kernel_sources_sha16": importlib.import_module("video-encoder_amd").kernel_sources_sha16(), "collected": time.strftime("%Y-%m-%d"),
+                     "how": "tools/final_batch.sh -> tools/sq_summary.py"}
+    json.dump(doc, open(path, "w"), indent=1)

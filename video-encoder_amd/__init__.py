@@ -183,6 +183,18 @@ def bind_hip(L):
     return L
 
 
+def kernel_sources_sha16():
+    """Digest of the device sources (csrc/*.hip, *.h): measurements kept under profiles/ carry it, and bench.py quotes a
+    kept counter value only while it still describes the kernels that are running."""
+    import glob
+    import hashlib
+    md = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h"))):
+        md.update(os.path.basename(f).encode())
+        md.update(open(f, "rb").read())
+    return md.hexdigest()[:16]
+
+
 def hip_lib():
     global _hip
     if _hip is None:

@@ -21,7 +21,7 @@
 #include "venc_inter2.hip"
 #include "venc_me2.hip"
 #ifdef VENC_LEGACY_KERNELS
-#include "venc_me.hip"
+#include "legacy/venc_me.hip"
 #endif
 #include "venc_me3.hip"
 #include "venc_subpel.hip"

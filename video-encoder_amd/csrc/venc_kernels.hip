@@ -111,140 +111,9 @@ DEVFN uint32_t wave_scan_incl(uint32_t v) {
     return v;
 }
 
-#ifdef VENC_LEGACY_KERNELS /* first-generation kernels: built into libvenc_hip_legacy.so only (on-GPU test oracles), not into the product library */
-/* ================================================================== k_me
- * One block = 8 horizontally adjacent macroblocks of one MB row; one half-wave
- * (32 lanes) per macroblock.  Lane l of a half-wave owns displacement column
- * dx = l - 16 and keeps 33 accumulators (one per dy) in VGPRs.  Each of the 48
- * window rows is fetched from LDS once per lane (5 dwords + 4 v_alignbyte) and
- * reused for up to 16 (cur row, dy) pairs with v_sad_u8, so the inner loop is
- * ~88 % SAD instructions.  The dx = +16 column is swept separately.  The argmin
- * uses the total-order key (sad << 11) | rank (spec/CODEC.md section ME).
- */
-#define ME_TILE 8
-#define ME_WDW (ME_TILE * 4 + 8) /* window row in dwords: 160 bytes */
-
-/* exhaustive search of one macroblock by one half-wave; returns the minimal key, identical in all 32 lanes */
-DEVFN uint32_t me_dense_half(const uint32_t *s_win, const uint32_t *s_cur, const uint16_t *s_rank, int mbi, int l32) {
-    uint32_t c[16][4];
-#pragma unroll
-    for (int y = 0; y < 16; y++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) c[y][j] = s_cur[y * (ME_TILE * 4) + mbi * 4 + j];
-
-    uint32_t acc[33];
-#pragma unroll
-    for (int i = 0; i < 33; i++) acc[i] = 0;
-
-    const int boff = mbi * 16 + l32; /* window byte column of displacement dx = l32 - 16 */
-    const int dw = boff >> 2;
-    const uint32_t sh = (uint32_t)(boff & 3);
-#pragma unroll
-    for (int r = 0; r < 48; r++) {
-        const uint32_t *row = s_win + r * ME_WDW + dw;
-        uint32_t d0 = row[0], d1 = row[1], d2 = row[2], d3 = row[3], d4 = row[4];
-        uint32_t r0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-        uint32_t r1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        uint32_t r2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-        uint32_t r3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-#pragma unroll
-        for (int y = 0; y < 16; y++) {
-            const int dyi = r - y; /* dy + 16 */
-            if (dyi >= 0 && dyi <= 32) {
-                uint32_t a = acc[dyi];
-                a = __builtin_amdgcn_sad_u8(r0, c[y][0], a);
-                a = __builtin_amdgcn_sad_u8(r1, c[y][1], a);
-                a = __builtin_amdgcn_sad_u8(r2, c[y][2], a);
-                a = __builtin_amdgcn_sad_u8(r3, c[y][3], a);
-                acc[dyi] = a;
-            }
-        }
-    }
-    uint32_t best = 0xffffffffu;
-#pragma unroll
-    for (int dyi = 0; dyi < 33; dyi++) {
-        uint32_t key = (acc[dyi] << 11) | s_rank[dyi * 33 + l32];
-        best = min(best, key);
-    }
-    /* displacement column dx = +16 (window byte column mbi*16 + 32: dword aligned) */
-    for (int dyi = l32; dyi < 33; dyi += 32) {
-        uint32_t a = 0;
-#pragma unroll
-        for (int y = 0; y < 16; y++) {
-            const uint32_t *row = s_win + (y + dyi) * ME_WDW + mbi * 4 + 8;
-            a = __builtin_amdgcn_sad_u8(row[0], c[y][0], a);
-            a = __builtin_amdgcn_sad_u8(row[1], c[y][1], a);
-            a = __builtin_amdgcn_sad_u8(row[2], c[y][2], a);
-            a = __builtin_amdgcn_sad_u8(row[3], c[y][3], a);
-        }
-        uint32_t key = (a << 11) | s_rank[dyi * 33 + 32];
-        best = min(best, key);
-    }
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, m));
-    return best;
-}
-
-__global__ __launch_bounds__(256) void k_me_dense(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ uint32_t s_win[48 * ME_WDW];
-    __shared__ uint32_t s_cur[16 * ME_TILE * 4];
-    __shared__ uint16_t s_rank[VENC_ME_CANDS];
-
-    const int item = blockIdx.z, my = S.row0 + blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
-    const int x0 = tx * ME_TILE * 16, y0 = my * 16;
-    int rstride;
-    const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
-    int cstride, pw, ph;
-    const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
-
-    for (int i = tid; i < VENC_ME_CANDS; i += 256) s_rank[i] = B.me_rank[i];
-
-    const bool xin = (x0 - 16 >= 0) && (x0 + ME_TILE * 16 + 16 <= g.cw);
-    for (int i = tid; i < 48 * ME_WDW; i += 256) {
-        int r = i / ME_WDW, d = i - r * ME_WDW;
-        int ry = clampi(y0 - 16 + r, 0, g.ch - 1);
-        int xb = x0 - 16 + 4 * d;
-        const uint8_t *row = ref + (size_t)ry * rstride;
-        uint32_t v;
-        if (xin) {
-            v = *(const uint32_t *)(row + xb);
-        } else {
-            v = (uint32_t)row[clampi(xb, 0, g.cw - 1)] | ((uint32_t)row[clampi(xb + 1, 0, g.cw - 1)] << 8) |
-                ((uint32_t)row[clampi(xb + 2, 0, g.cw - 1)] << 16) | ((uint32_t)row[clampi(xb + 3, 0, g.cw - 1)] << 24);
-        }
-        s_win[i] = v;
-    }
-    const bool cur_fast = ((g.w & 3) == 0) && (x0 + ME_TILE * 16 <= g.w);
-    for (int i = tid; i < 16 * ME_TILE * 4; i += 256) {
-        int r = i / (ME_TILE * 4), d = i - r * (ME_TILE * 4);
-        int sy = min(y0 + r, g.h - 1);
-        int xb = x0 + 4 * d;
-        const uint8_t *row = cur + (size_t)sy * cstride;
-        uint32_t v;
-        if (cur_fast) {
-            v = *(const uint32_t *)(row + xb);
-        } else {
-            v = (uint32_t)row[min(xb, g.w - 1)] | ((uint32_t)row[min(xb + 1, g.w - 1)] << 8) |
-                ((uint32_t)row[min(xb + 2, g.w - 1)] << 16) | ((uint32_t)row[min(xb + 3, g.w - 1)] << 24);
-        }
-        s_cur[i] = v;
-    }
-    __syncthreads();
-
-    const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l32 = lane & 31;
-    const int mbi = wave * 2 + half;
-    const int mx = tx * ME_TILE + mbi;
-
-    const uint32_t best = me_dense_half(s_win, s_cur, s_rank, mbi, l32);
-    if (l32 == 0 && mx < g.mbw) {
-        uint32_t cand = B.me_cand[best & 2047u];
-        int dx = (int)(cand & 255u) - 16, dy = (int)(cand >> 8) - 16;
-        B.mvsad[(size_t)item * g.nmb + my * g.mbw + mx] =
-            ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
-    }
-}
-
-#endif /* VENC_LEGACY_KERNELS */
+#ifdef VENC_LEGACY_KERNELS /* first-generation kernels: test-only library */
+#include "legacy/kernels_gen1_a.hip"
+#endif
 
 /* ================================================================== macroblock transform core
  * Lane roles inside a 32-lane macroblock team: l32 0..15 = luma4x4BlkIdx,
@@ -374,134 +243,9 @@ DEVFN void mb_store(int l32, bool valid, const mb_lane_out &o, int16_t *lv_mb, v
     }
 }
 
-#ifdef VENC_LEGACY_KERNELS
-/* ================================================================== k_inter
- * P_L0_16x16: half-wave per macroblock, 8 macroblocks per block. */
-__global__ __launch_bounds__(256) void k_inter(venc_geom g, venc_bufs B, venc_step S) {
-    const int item = blockIdx.z, tid = threadIdx.x;
-    const int lane = tid & 63, l32 = lane & 31, base = lane & 32;
-    const int mb_raw = S.mb0 + blockIdx.x * 8 + (tid >> 5);
-    const bool valid = mb_raw < S.mb1;
-    const int mb = valid ? mb_raw : S.mb1 - 1;
-    const int mx = mb % g.mbw, my = mb / g.mbw;
-    const bool luma = l32 < 16;
-    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
-    const int k = l32 & 3;
-    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
-    const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
-
-    const uint32_t mvs = B.mvsad[(size_t)item * g.nmb + mb];
-    const int dx = (int)(int8_t)(mvs & 255u), dy = (int)(int8_t)((mvs >> 8) & 255u);
-
-    int cstride, pw, ph, rstride, wstride;
-    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
-    const uint8_t *ref = rec_plane(B, g, S.ref, item, plane, rstride);
-    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
-    const int rw = luma ? g.cw : g.cw >> 1, rh = luma ? g.ch : g.ch >> 1;
-
-    int c[16], p[16];
-    /* current block: aligned dword rows when the plane geometry allows it, clamped bytes at the display edges */
-    const bool cur_fast = ((g.w & 7) == 0) && (px + 4 <= pw) && (py + 4 <= ph);
-    if (cur_fast) {
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-            const uint32_t v = *(const uint32_t *)(cur + (size_t)(py + y) * cstride + px);
-            c[4 * y] = (int)(v & 255u), c[4 * y + 1] = (int)((v >> 8) & 255u);
-            c[4 * y + 2] = (int)((v >> 16) & 255u), c[4 * y + 3] = (int)(v >> 24);
-        }
-    } else {
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++) c[4 * y + x] = cur[(size_t)min(py + y, ph - 1) * cstride + min(px + x, pw - 1)];
-    }
-    /* prediction: the reference block sits at an arbitrary byte offset; interior blocks fetch two
-     * aligned dwords per row and realign with v_alignbyte, blocks touching the frame edge clamp per sample */
-    const int xi = luma ? dx : dx >> 1, yi = luma ? dy : dy >> 1;
-    const int x0 = px + xi, y0 = py + yi;
-    const bool ref_fast = x0 >= 0 && x0 + 8 <= rw && y0 >= 0 && y0 + 5 <= rh;
-    if (luma) {
-        if (ref_fast) {
-            const uint32_t sh = (uint32_t)(x0 & 3);
-            const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
-#pragma unroll
-            for (int y = 0; y < 4; y++) {
-                const uint32_t *rw32 = (const uint32_t *)(rp + (size_t)y * rstride);
-                const uint32_t v = __builtin_amdgcn_alignbyte(rw32[1], rw32[0], sh);
-                p[4 * y] = (int)(v & 255u), p[4 * y + 1] = (int)((v >> 8) & 255u);
-                p[4 * y + 2] = (int)((v >> 16) & 255u), p[4 * y + 3] = (int)(v >> 24);
-            }
-        } else {
-#pragma unroll
-            for (int y = 0; y < 4; y++)
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-                    p[4 * y + x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
-        }
-    } else {
-        /* chroma MC, 8.4.2.2.2: integer luma mv -> eighth-sample chroma mv (frac 0 or 4) */
-        const int xf = (dx & 1) * 4, yf = (dy & 1) * 4;
-        int smp[5][5];
-        if (ref_fast) {
-            const uint32_t sh = (uint32_t)(x0 & 3);
-            const uint8_t *rp = ref + (size_t)y0 * rstride + (x0 & ~3);
-#pragma unroll
-            for (int y = 0; y < 5; y++) {
-                const uint32_t *rw32 = (const uint32_t *)(rp + (size_t)y * rstride);
-                const uint32_t d0 = rw32[0], d1 = rw32[1];
-                const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                const uint32_t e = __builtin_amdgcn_alignbyte(0u, d1, sh); /* byte x0+4 in its low byte */
-                smp[y][0] = (int)(v & 255u), smp[y][1] = (int)((v >> 8) & 255u);
-                smp[y][2] = (int)((v >> 16) & 255u), smp[y][3] = (int)(v >> 24);
-                smp[y][4] = (int)(e & 255u);
-            }
-        } else {
-#pragma unroll
-            for (int y = 0; y < 5; y++)
-#pragma unroll
-                for (int x = 0; x < 5; x++)
-                    smp[y][x] = ref[(size_t)clampi(y0 + y, 0, rh - 1) * rstride + clampi(x0 + x, 0, rw - 1)];
-        }
-#pragma unroll
-        for (int y = 0; y < 4; y++)
-#pragma unroll
-            for (int x = 0; x < 4; x++)
-                p[4 * y + x] = ((8 - xf) * (8 - yf) * smp[y][x] + xf * (8 - yf) * smp[y][x + 1] + (8 - xf) * yf * smp[y + 1][x] +
-                                xf * yf * smp[y + 1][x + 1] + 32) >> 6;
-    }
-    mb_lane_out o;
-    mb_code<false, false>(lane, c, p, g, o);
-
-    int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
-    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
-    mb_store(l32, valid, o, lv_mb, info, rec, wstride, px, py);
-
-    /* chroma DC records (slots 17, 18) and the empty luma-DC slot 16 */
-    int dc0 = __shfl(o.dclv, base | (l32 & 28) | 0), dc1 = __shfl(o.dclv, base | (l32 & 28) | 1);
-    int dc2 = __shfl(o.dclv, base | (l32 & 28) | 2), dc3 = __shfl(o.dclv, base | (l32 & 28) | 3);
-    if (valid && (l32 == 16 || l32 == 20)) { /* slot 16 (Intra16x16 luma DC) is never read for inter macroblocks */
-        uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
-        uint32_t a = ((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16);
-        uint32_t b = ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16);
-        dst[0] = make_uint4(a, b, 0, 0);
-    }
-    /* coded_block_pattern from wave ballots */
-    const unsigned long long bal_nz = __ballot(o.nnz > 0);
-    const unsigned long long bal_dc = __ballot(o.dclv != 0);
-    const uint32_t hnz = (uint32_t)(bal_nz >> base), hdc = (uint32_t)(bal_dc >> base);
-    if (valid && l32 == 0) {
-        int cbpl = 0;
-#pragma unroll
-        for (int qd = 0; qd < 4; qd++)
-            if ((hnz >> (4 * qd)) & 15u) cbpl |= 1 << qd;
-        int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
-        info->cbp = (uint8_t)cbpl;
-        info->cbpc = (uint8_t)cbpc;
-        info->flags = 0;
-    }
-}
-
-#endif /* VENC_LEGACY_KERNELS */
+#ifdef VENC_LEGACY_KERNELS /* first-generation kernels: test-only library */
+#include "legacy/kernels_gen1_b.hip"
+#endif
 
 /* ================================================================== k_intra
  * Intra16x16 with DC prediction needs the reconstructed left and top
@@ -526,139 +270,9 @@ DEVFN void load_cur_rows(const uint8_t *cur, int cstride, int pw, int ph, int px
     }
 }
 
-#ifdef VENC_LEGACY_KERNELS
-__global__ __launch_bounds__(1024) void k_intra(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ int s_bot[2 * INTRA_MAX_WAVES][4][5];
-    const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
-    const int nw = blockDim.x >> 6;
-    const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
-    /* a macroblock needs 24 lanes: each HALF of a wave owns a macroblock row of the band (row wv and row wv + nw),
-     * so a block of 16 waves sweeps 32 rows in one pass (the 17-row slices of 2160p took two passes of 16 + 1) */
-    const int rw = wv + nw * (lane >> 5);
-    const int r0 = B.slice_first_row[s], r1 = B.slice_first_row[s + 1];
-    const bool luma = l32 < 16;
-    const int plane = luma ? 0 : 1 + (((l32 - 16) >> 2) & 1);
-    const int k = l32 & 3;
-    const int bx = luma ? blk_x(l32) * 4 : (k & 1) * 4, by = luma ? blk_y(l32) * 4 : (k >> 1) * 4;
-
-    int cstride, pw, ph, wstride;
-    const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
-    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
-
-    for (int cb = r0; cb < r1; cb += 2 * nw) {
-        const int nr = min(2 * nw, r1 - cb);
-        const int my = cb + rw;
-        const int steps = g.mbw + nr - 1;
-        int leftY = 0, leftC0 = 0, leftC1 = 0; /* per lane: sums relevant to this lane's plane */
-        /* the current block's pixels are fetched one macroblock ahead so that the load latency
-         * hides behind the previous macroblock's arithmetic instead of sitting on the dependency chain */
-        const bool cur_al = luma ? ((g.w & 3) == 0) : ((g.w & 7) == 0);
-        const int pyl = (luma ? my * 16 : my * 8) + by;
-        uint32_t cq[4] = {0, 0, 0, 0};
-        if (rw < nr) load_cur_rows(cur, cstride, pw, ph, bx, pyl, cur_al, cq);
-        for (int step = 0; step < steps; step++) {
-            const int mx = step - rw;
-            if (rw < nr && mx >= 0 && mx < g.mbw) {
-                uint32_t nq[4] = {0, 0, 0, 0};
-                if (mx + 1 < g.mbw) load_cur_rows(cur, cstride, pw, ph, (luma ? (mx + 1) * 16 : (mx + 1) * 8) + bx, pyl, cur_al, nq);
-                const int mb = my * g.mbw + mx;
-                const bool aL = mx > 0, aT = my > r0;
-                /* top sums: [0] luma, [1],[2] Cb halves, [3],[4] Cr halves */
-                int t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
-                if (aT) {
-                    if (rw > 0) {
-                        const int *sb = s_bot[rw - 1][mx & 3];
-                        t0 = sb[0], t1 = sb[1], t2 = sb[2], t3 = sb[3], t4 = sb[4];
-                    } else {
-                        /* row above belongs to the previous chunk of this slice: re-read its bottom lines */
-                        int ys, us;
-                        const uint8_t *ry = rec_plane(B, g, S.parity, item, 0, ys) + (size_t)(my * 16 - 1) * ys + mx * 16;
-                        const uint8_t *ru = rec_plane(B, g, S.parity, item, 1, us) + (size_t)(my * 8 - 1) * us + mx * 8;
-                        const uint8_t *rv = rec_plane(B, g, S.parity, item, 2, us) + (size_t)(my * 8 - 1) * us + mx * 8;
-                        for (int x = 0; x < 16; x++) t0 += ry[x];
-                        for (int x = 0; x < 4; x++) t1 += ru[x], t2 += ru[4 + x], t3 += rv[x], t4 += rv[4 + x];
-                    }
-                }
-                int pred;
-                if (luma) {
-                    pred = (aL && aT) ? (leftY + t0 + 16) >> 5 : aL ? (leftY + 8) >> 4 : aT ? (t0 + 8) >> 4 : 128;
-                } else {
-                    const int sT = plane == 1 ? ((k & 1) ? t2 : t1) : ((k & 1) ? t4 : t3);
-                    const int sL = (k >> 1) ? leftC1 : leftC0;
-                    bool useT = aT, useL = aL;
-                    if (k == 1 && aT) useL = false;
-                    if (k == 2 && aL) useT = false;
-                    pred = (useT && useL) ? (sT + sL + 4) >> 3 : useT ? (sT + 2) >> 2 : useL ? (sL + 2) >> 2 : 128;
-                }
-                const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
-                int c[16], p[16];
-#pragma unroll
-                for (int y = 0; y < 4; y++)
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        c[4 * y + x] = (int)((cq[y] >> (8 * x)) & 255u);
-                        p[4 * y + x] = pred;
-                    }
-#pragma unroll
-                for (int y = 0; y < 4; y++) cq[y] = nq[y];
-                mb_lane_out o;
-                mb_code<true, true>(lane, c, p, g, o);
-
-                int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
-                venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
-                const bool st = true; /* both halves of the wave carry a macroblock */
-                mb_store(l32, st, o, lv_mb, info, rec, wstride, px, py);
-                /* luma DC record (slot 16, zig-zag order) and chroma DC records */
-                if (st && luma) {
-                    const int rp = blk_y(l32) * 4 + blk_x(l32);
-                    int zi = 0;
-#pragma unroll
-                    for (int i = 0; i < 16; i++)
-                        if (venc_zigzag_ct(i) == rp) zi = i;
-                    lv_mb[16 * 16 + zi] = (int16_t)o.dclv;
-                }
-                int dc0 = __shfl(o.dclv, hbase | (l32 & 28) | 0), dc1 = __shfl(o.dclv, hbase | (l32 & 28) | 1);
-                int dc2 = __shfl(o.dclv, hbase | (l32 & 28) | 2), dc3 = __shfl(o.dclv, hbase | (l32 & 28) | 3);
-                if (st && (l32 == 16 || l32 == 20)) {
-                    uint4 *dst = (uint4 *)(lv_mb + (l32 == 16 ? 17 : 18) * 16);
-                    dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16),
-                                        ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
-                }
-                const uint32_t hnz = (uint32_t)(__ballot(o.nnz > 0) >> hbase), hdc = (uint32_t)(__ballot(o.dclv != 0) >> hbase);
-                if (l32 == 0) {
-                    int cbpl = (hnz & 0xffffu) ? 15 : 0;
-                    int cbpc = ((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0;
-                    info->cbp = (uint8_t)cbpl;
-                    info->cbpc = (uint8_t)cbpc;
-                    info->flags = 1 | (2 << 1);
-                    B.mvsad[(size_t)item * g.nmb + mb] = 0;
-                }
-                /* neighbour sums for the next macroblocks */
-                const int pb = o.rec[12] + o.rec[13] + o.rec[14] + o.rec[15];
-                const int pr = o.rec[3] + o.rec[7] + o.rec[11] + o.rec[15];
-                const int botY = __shfl(pb, hbase | 10) + __shfl(pb, hbase | 11) + __shfl(pb, hbase | 14) + __shfl(pb, hbase | 15);
-                const int rightY = __shfl(pr, hbase | 5) + __shfl(pr, hbase | 7) + __shfl(pr, hbase | 13) + __shfl(pr, hbase | 15);
-                const int bcb0 = __shfl(pb, hbase | 18), bcb1 = __shfl(pb, hbase | 19), bcr0 = __shfl(pb, hbase | 22), bcr1 = __shfl(pb, hbase | 23);
-                const int rcb0 = __shfl(pr, hbase | 17), rcb1 = __shfl(pr, hbase | 19), rcr0 = __shfl(pr, hbase | 21), rcr1 = __shfl(pr, hbase | 23);
-                leftY = rightY;
-                leftC0 = plane == 2 ? rcr0 : rcb0;
-                leftC1 = plane == 2 ? rcr1 : rcb1;
-                if (l32 == 0) {
-                    int *sb = s_bot[rw][mx & 3];
-                    sb[0] = botY, sb[1] = bcb0, sb[2] = bcb1, sb[3] = bcr0, sb[4] = bcr1;
-                }
-            }
-            /* LDS-only barrier: __syncthreads() also waits for every global store and for the prefetch
-             * (s_waitcnt vmcnt(0)), which put a memory round trip on each step of the dependency chain */
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-        }
-        __syncthreads(); /* the next pass re-reads this pass's last reconstructed row from memory */
-    }
-}
-
-#endif /* VENC_LEGACY_KERNELS */
+#ifdef VENC_LEGACY_KERNELS /* first-generation kernels: test-only library */
+#include "legacy/kernels_gen1_c.hip"
+#endif
 
 /* ================================================================== k_cavlc
  * Half-wave per macroblock, one lane per syntax element group, in syntax order:
