@@ -219,7 +219,7 @@ static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, cons
     const int wmax = cap >= 1 && cap < DBK_MAX_WAVES ? cap : DBK_MAX_WAVES;
     const int waves = max_rows < wmax ? max_rows : wmax;
     prof_begin(c, KID_DEBLOCK, st);
-    hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), 0, st, g, b, S, planes);
+    hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), (size_t)waves * sizeof(dbk_strip), st, g, b, S, planes);
     prof_end(c, st);
 }
 /* the chroma transform of the last P step runs on the second stream: anything on the main stream that touches chroma
