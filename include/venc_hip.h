@@ -90,13 +90,17 @@ int venc_n_slices(const venc_ctx *c);
 size_t venc_frame_bytes(const venc_ctx *c); /* w*h*3/2: size of one input slot */
 
 /* Input.  venc_upload copies host planes into pool slot `slot` (async on the
- * copy stream); the source may be reused once venc_upload_sync() returns.
+ * copy stream); the source may be reused once venc_upload_sync() returns
+ * (venc_upload_sync_slot: once the copy into that slot is done -- callers that
+ * keep several pictures in flight).  Both wait for copies only, never for kernels.
  * venc_set_input borrows caller-owned device memory laid out as consecutive
  * I420 frames (frame_stride bytes apart, pointer and stride multiples of 16)
  * instead of the internal pool. */
 int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int stride_y, const uint8_t *u, int stride_u,
                 const uint8_t *v, int stride_v);
 int venc_upload_sync(venc_ctx *c);
+int venc_upload_sync_slot(venc_ctx *c, int slot);
+int venc_set_copy_streams(venc_ctx *c, int n); /* 1 (default) or 2: consecutive venc_upload calls' copies on two streams in turn */
 int venc_set_input(venc_ctx *c, const void *d_frames, size_t frame_stride, int n_frames);
 void *venc_input_slot_ptr(venc_ctx *c, int slot); /* device pointer of an internal pool slot */
 /* pinned host allocation helpers used by x264_picture_alloc (av_encode.c:415) */

@@ -127,6 +127,12 @@ typedef struct x264_param_t {
          * inside every slice (disable_deblocking_filter_idc = 2: slices, and with them GPU bands, stay independent;
          * x264_param_default_preset's default), 0 = off (what bench.py measures) */
         int i_deblock;
+        /* Input pictures the caller rotates through.  1 (default) = the reference's shape: ONE pic_in, rewritten right after
+         * every x264_encoder_encode (av_encode.c:543-547, :970), so the call returns only when its H2D copy is done.
+         * n >= 2 = the caller fills n pictures in turn and promises not to touch a picture until n - 1 further calls have
+         * returned: the call then waits for the copy issued n - 1 calls earlier, and the host's work between two calls
+         * overlaps the copy in flight. */
+        int i_input_depth;
     } hip;
     char psz_preset[16], psz_tune[16], psz_profile[16];
 } x264_param_t;
@@ -192,6 +198,14 @@ typedef struct {
     uint64_t pass_end_ns[X264_VENC_TALLY_PASSES];
 } x264_venc_tally;
 int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int payload_bytes, const x264_picture_t *pic_out);
+
+/* The reference's own loop over host frames, in C, for measurements (what bench.py's "pcie_inclusive" leg times): for every
+ * frame of `repeats` passes over clip_frames tight I420 frames in (pinned) host memory -- pic_in's planes point at the
+ * frame, i_type / i_pts as av_encode.c:543-544, x264_encoder_encode (av_encode.c:970), the sink on every output -- then
+ * the flush loop of av_encode.c:1076-1083.  Nothing but the eight public entry points is used.  Returns the frames
+ * delivered, or < 0. */
+int x264_venc_encode_host_frames(x264_t *h, const uint8_t *frames, uint64_t frame_stride, int width, int height, int clip_frames,
+                                 int repeats, x264_venc_sink sink, void *user);
 /* the venc_ctx* behind an encoder (for venc_profile / venc_debug_read) */
 void *x264_venc_engine(x264_t *h);
 

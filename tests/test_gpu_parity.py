@@ -136,6 +136,28 @@ def test_x264_api_bitstream_matches_oracle(venc, orc, w, h, qp, slices, keyint, 
         assert np.array_equal(dec.planes()[0], enc.recon()[0])
 
 
+@pytest.mark.parametrize("gop_batch,depth", [(1, 2), (4, 2), (4, 3)])
+def test_rotating_input_pictures_equal_the_single_picture_stream(venc, gop_batch, depth):
+    """hip.i_input_depth = n: the caller fills n pictures in turn and x264_encoder_encode waits for the H2D copy issued
+    n - 1 calls earlier instead of its own (include/x264.h).  Every picture is poisoned as soon as the contract lets the
+    caller touch it again: the stream must still equal the one-picture stream."""
+    w, h, n = 352, 288, 26
+    frames = [venc.synth_frame(w, h, t, 7) for t in range(n)]
+    a = _x264_stream(venc, frames, w, h, qp=28, slices=4, keyint=6, gop_batch=gop_batch)
+    enc = venc.X264Encoder(w, h, qp=28, slices=4, keyint=6, gop_batch=gop_batch, input_depth=depth)
+    got = []
+    for t, (y, u, v) in enumerate(frames):
+        if t >= depth:  # the picture about to be refilled was handed over `depth` calls ago: its copy must be done -- scribble over it first
+            for pl in enc._pic_planes[t % depth]:
+                pl[...] = 0xA5
+        f = enc.encode(y, u, v, t)
+        if f is not None:
+            got.append(f)
+    got += enc.flush()
+    enc.close()
+    assert [f.payload for f in got] == [f.payload for f in a]
+
+
 def test_gop_batched_equals_streaming(venc):
     w, h, n = 352, 288, 40
     frames = [venc.synth_frame(w, h, t, 99) for t in range(n)]

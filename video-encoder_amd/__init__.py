@@ -80,7 +80,7 @@ class _Hip(C.Structure):
     _fields_ = [("i_device", C.c_int), ("i_gop_batch", C.c_int), ("i_gop_base", C.c_int),
                 ("i_slice_first", C.c_int), ("i_slice_count", C.c_int), ("pf_exchange", EXCHANGE_FN),
                 ("p_exchange_user", C.c_void_p), ("i_rccl_world", C.c_int), ("i_rccl_rank", C.c_int),
-                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128), ("i_intra_modes", C.c_int), ("i_subpel", C.c_int), ("i_deblock", C.c_int)]
+                ("i_halo_rows", C.c_int), ("rccl_id", C.c_ubyte * 128), ("i_intra_modes", C.c_int), ("i_subpel", C.c_int), ("i_deblock", C.c_int), ("i_input_depth", C.c_int)]
 
 
 class X264Param(C.Structure):
@@ -495,7 +495,7 @@ class X264Encoder:
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
                  tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0,
-                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0, deblock=False):
+                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0, deblock=False, input_depth=1):
         """slice_first / slice_count / exchange: slice-parallel multi-GPU mode (include/x264.h, hip extension);
         exchange(engine_view, n_items) is called after every picture that a P picture follows.
         rccl = (world, rank, id_bytes, halo_rows): the engine does the exchange itself in C over RCCL
@@ -521,6 +521,7 @@ class X264Encoder:
         p.hip.i_intra_modes = int(intra_modes)
         p.hip.i_subpel = int(subpel)  # (likewise: the C API's presets refine to quarter samples)
         p.hip.i_deblock = int(bool(deblock))  # (and filter in the loop)
+        p.hip.i_input_depth = int(input_depth)
         if rccl is not None:
             world, rank, ident, halo = rccl
             p.hip.i_rccl_world, p.hip.i_rccl_rank, p.hip.i_halo_rows = world, rank, halo
@@ -542,17 +543,24 @@ class X264Encoder:
         self.h = self.L.x264_encoder_open(C.byref(p))
         if not self.h:
             raise VencError("x264: failed to initialize encoder (no HIP device or bad parameters)")
-        self.pic_in, self.pic_out = X264Picture(), X264Picture()
-        if self.L.x264_picture_alloc(C.byref(self.pic_in), X264_CSP_I420, width, height) != 0:
-            raise VencError("x264: could not allocate input picture")
+        self.pic_out = X264Picture()
         self.width, self.height = width, height
-        self._planes = [np.ctypeslib.as_array(self.pic_in.img.plane[0], (height, width)),
-                        np.ctypeslib.as_array(self.pic_in.img.plane[1], (height // 2, width // 2)),
-                        np.ctypeslib.as_array(self.pic_in.img.plane[2], (height // 2, width // 2))]
+        # hip.i_input_depth pictures, filled in turn by encode() (1: the reference's single pic_in)
+        self._pics, self._pic_planes, self._n_enc = [], [], 0
+        for _ in range(max(1, int(input_depth))):
+            pic = X264Picture()
+            if self.L.x264_picture_alloc(C.byref(pic), X264_CSP_I420, width, height) != 0:
+                raise VencError("x264: could not allocate input picture")
+            self._pics.append(pic)
+            self._pic_planes.append([np.ctypeslib.as_array(pic.img.plane[0], (height, width)),
+                                     np.ctypeslib.as_array(pic.img.plane[1], (height // 2, width // 2)),
+                                     np.ctypeslib.as_array(pic.img.plane[2], (height // 2, width // 2))])
+        self.pic_in, self._planes = self._pics[0], self._pic_planes[0]
 
     def close(self):
         if getattr(self, "h", None):
-            self.L.x264_picture_clean(C.byref(self.pic_in))
+            for pic in self._pics:
+                self.L.x264_picture_clean(C.byref(pic))
             self.L.x264_encoder_close(self.h)
             self.h = None
 
@@ -574,6 +582,9 @@ class X264Encoder:
 
     def encode(self, y, u, v, pts):
         """One call of x264_encoder_encode(); returns an EncodedFrame or None (frame buffered)."""
+        k = self._n_enc % len(self._pics)
+        self._n_enc += 1
+        self.pic_in, self._planes = self._pics[k], self._pic_planes[k]
         self.pic_in.i_type = X264_TYPE_AUTO
         self.pic_in.i_pts = pts
         np.copyto(self._planes[0], y)

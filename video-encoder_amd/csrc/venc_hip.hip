@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/venc_hip.h"
 #include "venc_kernels.hip"
@@ -76,9 +77,12 @@ struct venc_ctx {
     hipStream_t stream2; /* entropy chain of the same step: k_cavlc, k_scan, k_pack -- overlaps the next step's main chain */
     hipStream_t stream_copy; /* host -> HBM ingest (venc_upload): overlaps both kernel chains; the main chain waits for a slot's copy
                                 event only when a step reads that slot */
+    hipStream_t stream_copy2; /* odd slots' copies when the caller keeps two pictures in flight (venc_set_copy_streams) */
+    int n_copy_streams;
     hipEvent_t *ev_copy;     /* [in_slots] copy of the slot's frame complete */
     uint8_t *copy_pending;   /* [in_slots] ev_copy[slot] recorded and not yet waited for by the main chain */
     int last_copy_slot;      /* slot of the most recent venc_upload (-1: none): what venc_upload_sync waits for */
+    int prev_copy_slot;      /* the one before (the other copy stream's last when two are in use) */
     hipEvent_t ev_main[2];            /* alternating: main chains of an entropy batch done */
     int ev_main_next;
     hipEvent_t ev_luma[2];            /* alternating: search + luma transform of a P step done (the chroma launch on stream 2 waits) */
@@ -247,6 +251,7 @@ extern "C" void venc_close(venc_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rccl_release(c);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
+    if (c->stream_copy2) (void)hipStreamSynchronize(c->stream_copy2);
     if (c->stream_copy) (void)hipStreamSynchronize(c->stream_copy);
     if (c->ev)
         for (int i = 0; i < c->n_events; i++)
@@ -258,6 +263,7 @@ extern "C" void venc_close(venc_ctx *c) {
     free(c->ev_copy);
     free(c->copy_pending);
     if (c->stream_copy) (void)hipStreamDestroy(c->stream_copy);
+    if (c->stream_copy2) (void)hipStreamDestroy(c->stream_copy2);
     for (int i = 0; i < 2; i++) {
         if (c->ev_main[i]) (void)hipEventDestroy(c->ev_main[i]);
         if (c->ev_luma[i]) (void)hipEventDestroy(c->ev_luma[i]);
@@ -404,11 +410,14 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
             OPEN_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     }
     OPEN_OK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream_copy2, hipStreamNonBlocking));
     c->n_events = cfg->out_slots + 2 > VENC_EVENTS_MIN ? cfg->out_slots + 2 : VENC_EVENTS_MIN;
     c->ev = (hipEvent_t *)calloc((size_t)c->n_events, sizeof(hipEvent_t));
     c->ev_copy = (hipEvent_t *)calloc((size_t)(cfg->in_slots > 0 ? cfg->in_slots : 1), sizeof(hipEvent_t));
     c->copy_pending = (uint8_t *)calloc((size_t)(cfg->in_slots > 0 ? cfg->in_slots : 1), 1);
     c->last_copy_slot = -1;
+    c->prev_copy_slot = -1;
+    c->n_copy_streams = 1;
     if (!c->ev || !c->ev_copy || !c->copy_pending) {
         SET_ERR("venc_open: out of host memory");
         venc_close(c);
@@ -734,7 +743,9 @@ extern "C" int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int sy, cons
      * that must get its picture back (venc_upload_sync) waits for the copy alone, not for the kernel chain.  The pool slot is
      * free to overwrite: the caller reuses a slot only after the frame that last used it was delivered (its step complete).
      * Tight planes in one pinned allocation (what x264_picture_alloc hands out) go as ONE copy. */
-    hipStream_t sc = c->stream_copy;
+    /* one stream, or two taken in turn (venc_set_copy_streams: callers that keep two pictures in flight): a lone 3.1 MB copy per
+     * call tops out at 43 GB/s whatever waits for it, two in flight on two streams carry 52 (tools/h2d_ubench.hip) */
+    hipStream_t sc = c->n_copy_streams > 1 && (slot & 1) ? c->stream_copy2 : c->stream_copy;
     const size_t ysz = (size_t)w * h;
     if (sy == w && su == w / 2 && sv == w / 2 && u == y + ysz && v == u + ysz / 4) {
         HIP_OK(hipMemcpyAsync(d, y, ysz * 3 / 2, hipMemcpyHostToDevice, sc));
@@ -745,14 +756,44 @@ extern "C" int venc_upload(venc_ctx *c, int slot, const uint8_t *y, int sy, cons
     }
     HIP_OK(hipEventRecord(c->ev_copy[slot], sc));
     c->copy_pending[slot] = 1;
+    c->prev_copy_slot = c->last_copy_slot;
     c->last_copy_slot = slot;
     return 0;
 }
 /* the source planes of every venc_upload so far may be reused (waits for the copies only, never for kernels) */
+/* A frame's copy takes tens of microseconds (3.1 MB at 1080p: ~57 us at 55 GB/s) and the caller sits in the call that waits
+ * for it: poll the event for a while before handing the thread to the runtime's blocking wait, whose wake-up costs about as
+ * much as the copy itself (x264_encoder_encode from pinned host frames: 35 -> see DESIGN.md section 2 GB/s of H2D). */
+static int wait_copy_event(hipEvent_t ev) {
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) {
+            SET_ERR("hipEventQuery failed: %s", hipGetErrorString(e));
+            return -1;
+        }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 2000000ll) break; /* 2 ms: something else holds the copy up */
+    }
+    HIP_OK(hipEventSynchronize(ev));
+    return 0;
+}
 extern "C" int venc_upload_sync(venc_ctx *c) {
     if (c->last_copy_slot < 0) return 0;
-    HIP_OK(hipEventSynchronize(c->ev_copy[c->last_copy_slot])); /* one stream: the last copy covers the earlier ones */
+    if (c->n_copy_streams > 1 && c->prev_copy_slot >= 0 && wait_copy_event(c->ev_copy[c->prev_copy_slot]) != 0) return -1; /* the other stream's last */
+    return wait_copy_event(c->ev_copy[c->last_copy_slot]); /* per stream the last copy covers the earlier ones */
+}
+/* copies of consecutive venc_upload calls on two streams in turn (n = 2) or all on one (n = 1, the default) */
+extern "C" int venc_set_copy_streams(venc_ctx *c, int n) {
+    if (!c || n < 1 || n > 2) return -1;
+    c->n_copy_streams = n;
     return 0;
+}
+extern "C" int venc_upload_sync_slot(venc_ctx *c, int slot) {
+    if (slot < 0 || slot >= c->cfg.in_slots || !c->ev_copy) return 0; /* nothing was ever copied into it */
+    return wait_copy_event(c->ev_copy[slot]);
 }
 
 extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, const int *out_slots, int is_idr,

@@ -53,6 +53,7 @@ struct x264_t {
     x264_param_t param;
     venc_ctx *ctx;
     int qp, keyint, gop_batch, unit; /* unit = frames per scheduling unit (1 or G*keyint) */
+    int input_depth;                 /* hip.i_input_depth: pictures the caller rotates through (1: the reference's one pic_in) */
     int delay;                       /* frames between submission and delivery */
     int pool;                        /* in/out slots */
     int64_t n_in, n_out, n_launched;
@@ -185,6 +186,7 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     h->keyint = param->i_keyint_max > 0 ? param->i_keyint_max : 30;
     h->gop_counter = param->hip.i_gop_base > 0 ? param->hip.i_gop_base : 0;
     h->gop_batch = param->hip.i_gop_batch > 1 ? param->hip.i_gop_batch : 1;
+    h->input_depth = param->hip.i_input_depth > 1 ? param->hip.i_input_depth : 1;
     if (h->gop_batch > VENC_MAX_ITEMS) h->gop_batch = VENC_MAX_ITEMS;
     if (h->gop_batch > 1) {
         h->unit = h->gop_batch * h->keyint;
@@ -218,6 +220,7 @@ x264_t *x264_encoder_open(x264_param_t *param) {
         free(h);
         return NULL;
     }
+    if (h->input_depth > 1) (void)venc_set_copy_streams(h->ctx, 2); /* two pictures in flight: their copies on two streams in turn */
     h->ring = (shim_frame *)calloc((size_t)h->pool, sizeof(shim_frame));
     h->seq.width = param->i_width;
     h->seq.height = param->i_height;
@@ -521,7 +524,10 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
             return -1;
         /* the caller rewrites pic_in right after this call (av_encode.c:545): wait for the ingest copy -- on its own stream,
          * so this does not wait for the kernels of earlier frames, which keep running beside the copy of the next frame */
-        if (venc_upload_sync(h->ctx) != 0) return -1;
+        if (h->input_depth > 1) { /* hip.i_input_depth: the picture handed over input_depth - 1 calls ago is the next one the caller fills */
+            if (f >= h->input_depth - 1 && venc_upload_sync_slot(h->ctx, (int)((f - (h->input_depth - 1)) % h->pool)) != 0) return -1;
+        } else if (venc_upload_sync(h->ctx) != 0)
+            return -1;
         h->n_in++;
         if (launch_pending(h, 0) != 0) return -1;
         if (h->n_in - h->n_out <= h->delay) return 0;
@@ -657,6 +663,45 @@ int x264_venc_tally_sink(void *user, const x264_nal_t *nals, int nal_count, int 
         t->pass_end_ns[t->passes++] = (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
     }
     return 0;
+}
+
+/* the reference's loop (av_encode.c:940-980, :1076-1083) over frames in host memory, through the public entry points only */
+int x264_venc_encode_host_frames(x264_t *h, const uint8_t *frames, uint64_t frame_stride, int width, int height, int clip_frames,
+                                 int repeats, x264_venc_sink sink, void *user) {
+    if (!h || !frames || clip_frames < 1 || repeats < 1 || width <= 0 || height <= 0) return -1;
+    x264_picture_t pic_in, pic_out;
+    memset(&pic_in, 0, sizeof(pic_in));
+    memset(&pic_out, 0, sizeof(pic_out));
+    pic_in.img.i_csp = X264_CSP_I420;
+    pic_in.img.i_plane = 3;
+    pic_in.img.i_stride[0] = width;
+    pic_in.img.i_stride[1] = pic_in.img.i_stride[2] = width / 2;
+    const size_t ysz = (size_t)width * height;
+    x264_nal_t *nals;
+    int nal_count, delivered = 0;
+    for (int64_t k = 0; k < (int64_t)clip_frames * repeats; k++) {
+        uint8_t *base = (uint8_t *)frames + (size_t)(k % clip_frames) * frame_stride;
+        pic_in.i_type = X264_TYPE_AUTO;
+        pic_in.i_pts = k;
+        pic_in.img.plane[0] = base;
+        pic_in.img.plane[1] = base + ysz;
+        pic_in.img.plane[2] = base + ysz + ysz / 4;
+        const int payload = x264_encoder_encode(h, &nals, &nal_count, &pic_in, &pic_out);
+        if (payload < 0) return -1;
+        if (payload > 0) {
+            if (sink && sink(user, nals, nal_count, payload, &pic_out) != 0) return -1;
+            delivered++;
+        }
+    }
+    while (x264_encoder_delayed_frames(h) > 0) {
+        const int payload = x264_encoder_encode(h, &nals, &nal_count, NULL, &pic_out);
+        if (payload < 0) return -1;
+        if (payload > 0) {
+            if (sink && sink(user, nals, nal_count, payload, &pic_out) != 0) return -1;
+            delivered++;
+        }
+    }
+    return delivered;
 }
 
 void *x264_venc_engine(x264_t *h) { return h ? h->ctx : NULL; }
