@@ -108,6 +108,10 @@ int orc_enc_picture_qp(const orc_enc *e);                   /* QP of the last en
 /* luma prediction block at (xq, yq) quarter-sample units, 8.4.2.2.1 with clamped coordinates (orc_interp.h); dst is bw wide */
 void orc_luma_interp(const uint8_t *ref, int stride, int w, int h, int xq, int yq, int bw, int bh, uint8_t *dst);
 /* CAVLC residual block; coef[] in scan order; returns number of bits appended */
+/* Intra4x4 (8.3.1; orc_intra4.h): predictor `mode` (0 .. 8) from explicit neighbours, -1 if the mode needs samples that are missing */
+int orc_intra4_predict(const uint8_t top[8], const uint8_t left[4], int corner, int have_top, int have_left, int have_corner, int mode,
+                       uint8_t out[16]);
+int orc_intra4_topright_available(int bx, int by, int aT, int aTR);
 int orc_cavlc_block_bits(const int16_t *coef, int max_coef, int nC, uint8_t *out, size_t cap);
 /* emulation prevention: returns output size */
 size_t orc_escape(const uint8_t *rbsp, size_t n, uint8_t *out);

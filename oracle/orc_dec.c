@@ -16,6 +16,7 @@
  */
 #include "orc.h"
 #include "orc_interp.h"
+#include "orc_intra4.h"
 #include "orc_deblock.h"
 #include "orc_tables.h"
 
@@ -72,6 +73,8 @@ struct orc_dec {
     int8_t *mv;
     uint8_t *nnz_l, *nnz_cb, *nnz_cr;
     int *mb_slice; /* slice id of every MB of the current picture, -1 = not decoded */
+    uint8_t *mb_i4;  /* [mb] Intra4x4 */
+    int8_t *i4mode;  /* [mb][16] Intra4x4PredMode by luma4x4BlkIdx */
     uint8_t *mb_intra, *mb_qp, *mb_dbk; /* per MB: intra, QP_Y, in-loop filter on (disable_deblocking_filter_idc == 2) */
     int n_slices_seen;
     uint8_t *rbsp;
@@ -92,6 +95,8 @@ void orc_dec_close(orc_dec *d) {
     free(d->nnz_cr);
     free(d->mb_slice);
     free(d->mb_intra);
+    free(d->mb_i4);
+    free(d->i4mode);
     free(d->mb_qp);
     free(d->mb_dbk);
     free(d->rbsp);
@@ -149,6 +154,8 @@ static int parse_sps(orc_dec *d, br_t *b) {
         free(d->nnz_cr);
         free(d->mb_slice);
         free(d->mb_intra);
+    free(d->mb_i4);
+    free(d->i4mode);
         free(d->mb_qp);
         free(d->mb_dbk);
         size_t nmb = (size_t)mbw * mbh;
@@ -158,6 +165,8 @@ static int parse_sps(orc_dec *d, br_t *b) {
         d->nnz_cr = (uint8_t *)calloc(nmb * 4, 1);
         d->mb_slice = (int *)calloc(nmb, sizeof(int));
         d->mb_intra = (uint8_t *)calloc(nmb, 1);
+        d->mb_i4 = (uint8_t *)calloc(nmb, 1);
+        d->i4mode = (int8_t *)calloc(nmb * 16, 1);
         d->mb_qp = (uint8_t *)calloc(nmb, 1);
         d->mb_dbk = (uint8_t *)calloc(nmb, 1);
     }
@@ -463,82 +472,137 @@ static int decode_slice(orc_dec *d, br_t *b, int nal_type, int ref_idc) {
         int aL = mb_avail(d, mx - 1, my, sid), aT = mb_avail(d, mx, my - 1, sid);
         if (st == 2 || t >= 5) {
             if (st == 0) FAIL(d, "intra MB in P slice unsupported");
-            if (t < 1 || t > 24) FAIL(d, "mb_type %d unsupported in I slice", t);
-            int pm = (t - 1) & 3, cbpc = ((t - 1) >> 2) % 3, acf = (t - 1) >= 12;
-            if (br_ue(b) != 0) FAIL(d, "intra chroma pred mode unsupported");
-            qp += br_se(b);
-            int16_t dcl[16], ac[16][16];
-            memset(ac, 0, sizeof(ac));
-            if (parse_block(b, dcl, 16, luma_nc_d(d, mx, my, 0, 0, sid)) < 0) FAIL(d, "luma dc parse mb %d", mb);
-            memset(d->nnz_l + mb * 16, 0, 16);
-            if (acf)
+            int cbpc;
+            uint8_t *dst = d->cur[0] + (size_t)(my * 16) * d->cw + mx * 16;
+            d->mb_i4[mb] = (uint8_t)(t == 0);
+            memset(d->i4mode + (size_t)mb * 16, -1, 16);
+            if (t == 0) {
+                /* I_NxN (7.3.5, 7.3.5.1; Baseline: no transform_size_8x8_flag): Intra4x4 */
+                int8_t *own = d->i4mode + (size_t)mb * 16;
+                for (int k = 0; k < 16; k++) {
+                    const int bx = orc_blk_x[k], by = orc_blk_y[k];
+                    int mA, mB;
+                    if (bx > 0) mA = own[orc_i4_idx(bx - 1, by)];
+                    else if (aL) mA = d->mb_i4[mb - 1] ? d->i4mode[(size_t)(mb - 1) * 16 + orc_i4_idx(3, by)] : 2;
+                    else mA = -1;
+                    if (by > 0) mB = own[orc_i4_idx(bx, by - 1)];
+                    else if (aT) mB = d->mb_i4[mb - d->mbw] ? d->i4mode[(size_t)(mb - d->mbw) * 16 + orc_i4_idx(bx, 3)] : 2;
+                    else mB = -1;
+                    const int pm4 = orc_i4_pred_mode(mA, mB);
+                    if (br_get(b, 1))
+                        own[k] = (int8_t)pm4;
+                    else {
+                        const int rem = (int)br_get(b, 3);
+                        own[k] = (int8_t)(rem < pm4 ? rem : rem + 1);
+                    }
+                }
+                if (br_ue(b) != 0) FAIL(d, "intra chroma pred mode unsupported");
+                const int code = (int)br_ue(b);
+                if (code > 47) FAIL(d, "bad coded_block_pattern code %d", code);
+                const int cbp = orc_golomb_to_intra_cbp[code];
+                cbpc = cbp >> 4;
+                if (cbp) qp += br_se(b);
+                int16_t cf[16][16];
+                memset(cf, 0, sizeof(cf));
+                memset(d->nnz_l + mb * 16, 0, 16);
+                for (int q = 0; q < 4; q++)
+                    if (cbp & (1 << q))
+                        for (int k = 4 * q; k < 4 * q + 4; k++) {
+                            const int bx = orc_blk_x[k], by = orc_blk_y[k];
+                            const int n = parse_block(b, cf[k], 16, luma_nc_d(d, mx, my, bx, by, sid));
+                            if (n < 0) FAIL(d, "luma parse mb %d blk %d", mb, k);
+                            d->nnz_l[mb * 16 + 4 * by + bx] = (uint8_t)n;
+                        }
+                const int aTL = mb_avail(d, mx - 1, my - 1, sid), aTR = mb_avail(d, mx + 1, my - 1, sid);
+                for (int k = 0; k < 16; k++) {
+                    const int bx = orc_blk_x[k], by = orc_blk_y[k];
+                    orc_i4_nb nb;
+                    orc_i4_neighbours(dst, d->cw, bx, by, aL, aT, aTL, aTR, &nb);
+                    if (own[k] < 0 || own[k] > 8 || !orc_i4_mode_ok(&nb, own[k])) FAIL(d, "Intra4x4PredMode %d without its neighbours (mb %d blk %d)", own[k], mb, k);
+                    uint8_t pr[16];
+                    orc_i4_predict(&nb, own[k], pr);
+                    int dd[4][4];
+                    scale_block(cf[k], qp, 0, dd);
+                    inv_transform_add(dst + (size_t)(4 * by) * d->cw + 4 * bx, d->cw, pr, 4, dd);
+                }
+            } else {
+                if (t < 1 || t > 24) FAIL(d, "mb_type %d unsupported in I slice", t);
+                int pm = (t - 1) & 3, acf = (t - 1) >= 12;
+                cbpc = ((t - 1) >> 2) % 3;
+                if (br_ue(b) != 0) FAIL(d, "intra chroma pred mode unsupported");
+                qp += br_se(b);
+                int16_t dcl[16], ac[16][16];
+                memset(ac, 0, sizeof(ac));
+                if (parse_block(b, dcl, 16, luma_nc_d(d, mx, my, 0, 0, sid)) < 0) FAIL(d, "luma dc parse mb %d", mb);
+                memset(d->nnz_l + mb * 16, 0, 16);
+                if (acf)
+                    for (int k = 0; k < 16; k++) {
+                        int bx = orc_blk_x[k], by = orc_blk_y[k];
+                        int n = parse_block(b, ac[k] + 1, 15, luma_nc_d(d, mx, my, bx, by, sid));
+                        if (n < 0) FAIL(d, "luma ac parse mb %d blk %d", mb, k);
+                        d->nnz_l[mb * 16 + 4 * by + bx] = (uint8_t)n;
+                    }
+                /* Intra16x16 DC prediction */
+                int sum = 0, dcp;
+                if (aT)
+                    for (int x = 0; x < 16; x++) sum += dst[-(ptrdiff_t)d->cw + x];
+                if (aL)
+                    for (int y = 0; y < 16; y++) sum += dst[(size_t)y * d->cw - 1];
+                dcp = aT && aL ? (sum + 16) >> 5 : (aT || aL) ? (sum + 8) >> 4 : 128;
+                /* the 16x16 predictor (8.3.3.1-8.3.3.3): vertical = the row above, horizontal = the column to the left, DC */
+                uint8_t pred16[256];
+                if (pm == 0) {
+                    if (!aT) FAIL(d, "Intra16x16 vertical prediction without a macroblock above (mb %d)", mb);
+                    for (int y = 0; y < 16; y++) memcpy(pred16 + 16 * y, dst - (ptrdiff_t)d->cw, 16);
+                } else if (pm == 1) {
+                    if (!aL) FAIL(d, "Intra16x16 horizontal prediction without a macroblock to the left (mb %d)", mb);
+                    for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, dst[(size_t)y * d->cw - 1], 16);
+                } else if (pm == 3) {
+                    /* plane (8.3.3.4): p[x, -1], p[-1, y] and the corner p[-1, -1] as arrays indexed from -1 */
+                    if (!aT || !aL || !mb_avail(d, mx - 1, my - 1, sid)) FAIL(d, "Intra16x16 plane prediction without its neighbours (mb %d)", mb);
+                    int tp[17], lf[17];
+                    for (int i = -1; i < 16; i++) {
+                        tp[i + 1] = dst[-(ptrdiff_t)d->cw + i];
+                        lf[i + 1] = i < 0 ? dst[-(ptrdiff_t)d->cw - 1] : dst[(size_t)i * d->cw - 1];
+                    }
+                    int hh = 0, vv = 0;
+                    for (int k = 0; k <= 7; k++) {
+                        hh += (k + 1) * (tp[1 + 8 + k] - tp[1 + 6 - k]);
+                        vv += (k + 1) * (lf[1 + 8 + k] - lf[1 + 6 - k]);
+                    }
+                    const int pa = 16 * (lf[16] + tp[16]), pb = (5 * hh + 32) >> 6, pc = (5 * vv + 32) >> 6;
+                    for (int y = 0; y < 16; y++)
+                        for (int x = 0; x < 16; x++) {
+                            const int v = (pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5;
+                            pred16[16 * y + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+                        }
+                } else
+                    memset(pred16, dcp, 256);
+                /* luma DC: inverse zig-zag, 4x4 Hadamard, scaling (8.5.10) */
+                int c[4][4], f[4][4], tt[4][4];
+                for (int k = 0; k < 16; k++) c[orc_zigzag4x4[k] >> 2][orc_zigzag4x4[k] & 3] = dcl[k];
+                static const int A[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 4; j++) {
+                        tt[i][j] = 0;
+                        for (int k = 0; k < 4; k++) tt[i][j] += A[i][k] * c[k][j];
+                    }
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 4; j++) {
+                        f[i][j] = 0;
+                        for (int k = 0; k < 4; k++) f[i][j] += tt[i][k] * A[k][j];
+                    }
                 for (int k = 0; k < 16; k++) {
                     int bx = orc_blk_x[k], by = orc_blk_y[k];
-                    int n = parse_block(b, ac[k] + 1, 15, luma_nc_d(d, mx, my, bx, by, sid));
-                    if (n < 0) FAIL(d, "luma ac parse mb %d blk %d", mb, k);
-                    d->nnz_l[mb * 16 + 4 * by + bx] = (uint8_t)n;
+                    int dd[4][4];
+                    memset(dd, 0, sizeof(dd));
+                    scale_block(ac[k], qp, 1, dd);
+                    int ls = level_scale(qp, 0, 0);
+                    dd[0][0] = qp >= 36 ? (f[by][bx] * ls) << (qp / 6 - 6) : (f[by][bx] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+                    uint8_t pr[16];
+                    for (int y = 0; y < 4; y++) memcpy(pr + 4 * y, pred16 + 16 * (4 * by + y) + 4 * bx, 4);
+                    inv_transform_add(dst + (size_t)(4 * by) * d->cw + 4 * bx, d->cw, pr, 4, dd);
                 }
-            /* Intra16x16 DC prediction */
-            uint8_t *dst = d->cur[0] + (size_t)(my * 16) * d->cw + mx * 16;
-            int sum = 0, dcp;
-            if (aT)
-                for (int x = 0; x < 16; x++) sum += dst[-(ptrdiff_t)d->cw + x];
-            if (aL)
-                for (int y = 0; y < 16; y++) sum += dst[(size_t)y * d->cw - 1];
-            dcp = aT && aL ? (sum + 16) >> 5 : (aT || aL) ? (sum + 8) >> 4 : 128;
-            /* the 16x16 predictor (8.3.3.1-8.3.3.3): vertical = the row above, horizontal = the column to the left, DC */
-            uint8_t pred16[256];
-            if (pm == 0) {
-                if (!aT) FAIL(d, "Intra16x16 vertical prediction without a macroblock above (mb %d)", mb);
-                for (int y = 0; y < 16; y++) memcpy(pred16 + 16 * y, dst - (ptrdiff_t)d->cw, 16);
-            } else if (pm == 1) {
-                if (!aL) FAIL(d, "Intra16x16 horizontal prediction without a macroblock to the left (mb %d)", mb);
-                for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, dst[(size_t)y * d->cw - 1], 16);
-            } else if (pm == 3) {
-                /* plane (8.3.3.4): p[x, -1], p[-1, y] and the corner p[-1, -1] as arrays indexed from -1 */
-                if (!aT || !aL || !mb_avail(d, mx - 1, my - 1, sid)) FAIL(d, "Intra16x16 plane prediction without its neighbours (mb %d)", mb);
-                int tp[17], lf[17];
-                for (int i = -1; i < 16; i++) {
-                    tp[i + 1] = dst[-(ptrdiff_t)d->cw + i];
-                    lf[i + 1] = i < 0 ? dst[-(ptrdiff_t)d->cw - 1] : dst[(size_t)i * d->cw - 1];
-                }
-                int hh = 0, vv = 0;
-                for (int k = 0; k <= 7; k++) {
-                    hh += (k + 1) * (tp[1 + 8 + k] - tp[1 + 6 - k]);
-                    vv += (k + 1) * (lf[1 + 8 + k] - lf[1 + 6 - k]);
-                }
-                const int pa = 16 * (lf[16] + tp[16]), pb = (5 * hh + 32) >> 6, pc = (5 * vv + 32) >> 6;
-                for (int y = 0; y < 16; y++)
-                    for (int x = 0; x < 16; x++) {
-                        const int v = (pa + pb * (x - 7) + pc * (y - 7) + 16) >> 5;
-                        pred16[16 * y + x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
-                    }
-            } else
-                memset(pred16, dcp, 256);
-            /* luma DC: inverse zig-zag, 4x4 Hadamard, scaling (8.5.10) */
-            int c[4][4], f[4][4], tt[4][4];
-            for (int k = 0; k < 16; k++) c[orc_zigzag4x4[k] >> 2][orc_zigzag4x4[k] & 3] = dcl[k];
-            static const int A[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
-            for (int i = 0; i < 4; i++)
-                for (int j = 0; j < 4; j++) {
-                    tt[i][j] = 0;
-                    for (int k = 0; k < 4; k++) tt[i][j] += A[i][k] * c[k][j];
-                }
-            for (int i = 0; i < 4; i++)
-                for (int j = 0; j < 4; j++) {
-                    f[i][j] = 0;
-                    for (int k = 0; k < 4; k++) f[i][j] += tt[i][k] * A[k][j];
-                }
-            for (int k = 0; k < 16; k++) {
-                int bx = orc_blk_x[k], by = orc_blk_y[k];
-                int dd[4][4];
-                memset(dd, 0, sizeof(dd));
-                scale_block(ac[k], qp, 1, dd);
-                int ls = level_scale(qp, 0, 0);
-                dd[0][0] = qp >= 36 ? (f[by][bx] * ls) << (qp / 6 - 6) : (f[by][bx] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
-                uint8_t pr[16];
-                for (int y = 0; y < 4; y++) memcpy(pr + 4 * y, pred16 + 16 * (4 * by + y) + 4 * bx, 4);
-                inv_transform_add(dst + (size_t)(4 * by) * d->cw + 4 * bx, d->cw, pr, 4, dd);
             }
             /* chroma DC prediction */
             uint8_t pred[2][64];

@@ -13,6 +13,7 @@
  */
 #include "orc.h"
 #include "orc_interp.h"
+#include "orc_intra4.h"
 #include "orc_deblock.h"
 #include "orc_tables.h"
 
@@ -328,6 +329,9 @@ struct orc_enc {
     uint32_t *mb_bits;
     uint8_t *nnz_l, *nnz_cb, *nnz_cr;
     uint8_t *mb_cbp, *mb_i16flags, *mb_i16mode;
+    uint8_t *mb_i4;      /* [mb] the macroblock is coded Intra4x4 (I_NxN) */
+    int8_t *mb_i4mode;   /* [mb][16] Intra4x4PredMode by luma4x4BlkIdx (-1 everywhere in macroblocks that are not Intra4x4) */
+    uint8_t cbp_to_code_intra[48];
     uint16_t rank[33 * 33];
     uint8_t cbp_to_code[48];
     uint8_t **slice_buf;
@@ -399,9 +403,13 @@ orc_enc *orc_enc_open(const orc_params *p) {
     e->mb_cbp = (uint8_t *)calloc((size_t)nmb, 1);
     e->mb_i16flags = (uint8_t *)calloc((size_t)nmb, 1);
     e->mb_i16mode = (uint8_t *)calloc((size_t)nmb, 1);
+    e->mb_i4 = (uint8_t *)calloc((size_t)nmb, 1);
+    e->mb_i4mode = (int8_t *)malloc((size_t)nmb * 16);
+    memset(e->mb_i4mode, -1, (size_t)nmb * 16);
     for (int dy = -16; dy <= 16; dy++)
         for (int dx = -16; dx <= 16; dx++) e->rank[(dy + 16) * 33 + dx + 16] = (uint16_t)orc_me_rank(dx, dy);
     for (int i = 0; i < 48; i++) e->cbp_to_code[orc_golomb_to_inter_cbp[i]] = (uint8_t)i;
+    for (int i = 0; i < 48; i++) e->cbp_to_code_intra[orc_golomb_to_intra_cbp[i]] = (uint8_t)i;
     e->band_s0 = 0;
     e->band_s1 = e->p.n_slices;
     e->slice_buf = (uint8_t **)calloc((size_t)e->p.n_slices, sizeof(uint8_t *));
@@ -443,6 +451,8 @@ void orc_enc_close(orc_enc *e) {
     free(e->mb_cbp);
     free(e->mb_i16flags);
     free(e->mb_i16mode);
+    free(e->mb_i4);
+    free(e->mb_i4mode);
     free(e);
 }
 
@@ -620,6 +630,86 @@ static int chroma_cbp_and_nnz(orc_enc *e, int mb, const int16_t *lv) {
 }
 
 /* ---- Intra16x16 (DC prediction) macroblock: transform, quant, recon ---- */
+static void code_intra_chroma_and_flags(orc_enc *e, int mx, int my, int avail_l, int avail_t, int is_i4);
+
+/* test hooks: one Intra4x4 predictor from explicit neighbours, and the availability of a block's upper-right samples */
+int orc_intra4_predict(const uint8_t top[8], const uint8_t left[4], int corner, int have_top, int have_left, int have_corner, int mode,
+                       uint8_t out[16]) {
+    orc_i4_nb nb;
+    nb.top = have_top, nb.left = have_left, nb.corner = have_corner, nb.topright = have_top;
+    for (int i = 0; i < 8; i++) nb.t[i] = top[i];
+    for (int i = 0; i < 4; i++) nb.l[i] = left[i];
+    nb.c = corner;
+    if (mode < 0 || mode > 8 || !orc_i4_mode_ok(&nb, mode)) return -1;
+    orc_i4_predict(&nb, mode, out);
+    return 0;
+}
+int orc_intra4_topright_available(int bx, int by, int aT, int aTR) {
+    uint8_t px[64 * 64];
+    orc_i4_nb nb;
+    memset(px, 1, sizeof(px));
+    orc_i4_neighbours(px + 20 * 64 + 20, 64, bx, by, 1, aT, aT, aTR, &nb);
+    return nb.topright;
+}
+
+/* Intra4x4 luma of one macroblock (8.3.1, spec/CODEC.md section 3): blocks in luma4x4BlkIdx order, each predicted from the
+ * reconstruction so far by the usable mode with the smallest SAD against the source (the smaller mode number on ties),
+ * then transformed, quantised (all 16 coefficients, intra rounding) and reconstructed.  Returns 1 and leaves levels,
+ * counts, modes, the luma half of mb_cbp and the reconstruction in place iff the sum of the blocks' SADs is strictly
+ * below sad16; else returns 0 (levels and reconstruction are then overwritten by the Intra16x16 path). */
+static int code_luma_intra4x4(orc_enc *e, int mx, int my, int slice_first_row, long sad16) {
+    const int mb = my * e->mbw + mx, qp = e->qp_cur;
+    const int aL = mx > 0, aT = my > slice_first_row, aTL = aL && aT, aTR = aT && mx + 1 < e->mbw;
+    uint8_t *rec = e->rec[0] + (size_t)(my * 16) * e->cw + mx * 16;
+    const uint8_t *cur = e->cur[0] + (size_t)(my * 16) * e->cw + mx * 16;
+    int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
+    int8_t modes[16];
+    uint8_t nnz[16];
+    long total = 0;
+    for (int blk = 0; blk < 16; blk++) {
+        const int bx = orc_blk_x[blk], by = orc_blk_y[blk];
+        orc_i4_nb nb;
+        orc_i4_neighbours(rec, e->cw, bx, by, aL, aT, aTL, aTR, &nb);
+        uint8_t pred[16], bestp[16];
+        long bs = -1;
+        int bm = 2;
+        for (int m = 0; m < 9; m++) {
+            if (!orc_i4_mode_ok(&nb, m)) continue;
+            orc_i4_predict(&nb, m, pred);
+            long sd = 0;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) sd += abs((int)cur[(size_t)(4 * by + y) * e->cw + 4 * bx + x] - (int)pred[4 * y + x]);
+            if (bs < 0 || sd < bs) bs = sd, bm = m, memcpy(bestp, pred, 16);
+        }
+        total += bs;
+        modes[blk] = (int8_t)bm;
+        int16_t res[16], w[16], r[16];
+        int32_t d[16];
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) res[4 * y + x] = (int16_t)((int)cur[(size_t)(4 * by + y) * e->cw + 4 * bx + x] - (int)bestp[4 * y + x]);
+        orc_fdct4x4(res, w);
+        for (int i = 0; i < 16; i++) {
+            lv[blk * 16 + i] = (int16_t)orc_quant(w[orc_zigzag4x4[i]], qp, orc_zigzag4x4[i], 1);
+            d[orc_zigzag4x4[i]] = orc_dequant(lv[blk * 16 + i], qp, orc_zigzag4x4[i]);
+        }
+        orc_idct4x4(d, r);
+        for (int y = 0; y < 4; y++)
+            for (int x = 0; x < 4; x++) rec[(size_t)(4 * by + y) * e->cw + 4 * bx + x] = clip_u8((int)bestp[4 * y + x] + r[4 * y + x]);
+        nnz[blk] = (uint8_t)count_nz(lv + blk * 16, 0, 16);
+    }
+    if (!(total < sad16)) return 0;
+    int cbpl = 0;
+    for (int blk = 0; blk < 16; blk++) {
+        e->nnz_l[mb * 16 + 4 * orc_blk_y[blk] + orc_blk_x[blk]] = nnz[blk];
+        if (nnz[blk]) cbpl |= 1 << (blk >> 2);
+    }
+    memset(lv + 16 * 16, 0, 16 * sizeof(int16_t)); /* no Intra16x16 DC block */
+    memcpy(e->mb_i4mode + (size_t)mb * 16, modes, 16);
+    e->mb_i4[mb] = 1;
+    e->mb_cbp[mb] = (uint8_t)cbpl; /* (the chroma half follows) */
+    return 1;
+}
+
 static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
     int mb = my * e->mbw + mx;
     int qp = e->qp_cur;
@@ -649,6 +739,7 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
      * left, inside the slice (8.3.3) */
     uint8_t pred16[256];
     int mode = 2;
+    long best16 = 0; /* SAD of the chosen 16x16 predictor */
     memset(pred16, dcp, 256);
     if (e->p.intra_modes) {
         long sad[3] = {-1, -1, 0};
@@ -686,6 +777,7 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
                 }
             if (s3 < best) best = s3, mode = 3;
         }
+        best16 = best;
         if (mode == 3)
             memcpy(pred16, plane16, 256);
         else if (mode == 0)
@@ -694,6 +786,14 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
             for (int y = 0; y < 16; y++) memset(pred16 + 16 * y, rec[(size_t)y * e->cw - 1], 16);
     }
     e->mb_i16mode[mb] = (uint8_t)mode;
+    e->mb_i4[mb] = 0;
+    memset(e->mb_i4mode + (size_t)mb * 16, -1, 16);
+    /* intra_modes = 3: Intra4x4 (8.3.1) tried against the best Intra16x16 predictor; taken iff the sum of its blocks' SADs is
+     * strictly smaller than the 16x16 predictor's (spec/CODEC.md section 3) */
+    if (e->p.intra_modes >= 3 && code_luma_intra4x4(e, mx, my, slice_first_row, best16)) {
+        code_intra_chroma_and_flags(e, mx, my, avail_l, avail_t, 1);
+        return;
+    }
 
     int dc[16], ydc[16];
     for (int by = 0; by < 4; by++)
@@ -732,7 +832,15 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
     }
     if (!ac_flag) memset(e->nnz_l + mb * 16, 0, 16);
 
-    /* chroma DC prediction (8.3.4.1-8.3.4.3), per 4x4 chroma block */
+    code_intra_chroma_and_flags(e, mx, my, avail_l, avail_t, 0);
+    e->mb_cbp[mb] = (uint8_t)((e->mb_cbp[mb] & 0x30) | (ac_flag ? 15 : 0));
+}
+
+/* chroma of an intra macroblock (DC prediction, 8.3.4.1-8.3.4.3, per 4x4 chroma block) and the macroblock's flags; the
+ * luma half of mb_cbp is left to the caller (Intra16x16: all or nothing; Intra4x4: set by code_luma_intra4x4) */
+static void code_intra_chroma_and_flags(orc_enc *e, int mx, int my, int avail_l, int avail_t, int is_i4) {
+    int mb = my * e->mbw + mx;
+    int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     int cs = e->cw / 2;
     for (int plane = 1; plane <= 2; plane++) {
         uint8_t pred[64];
@@ -774,8 +882,8 @@ static void code_mb_intra(orc_enc *e, int mx, int my, int slice_first_row) {
         code_chroma(e, mx, my, plane, pred, 1, lv + (16 + plane) * 16, lv + (plane == 1 ? 19 : 23) * 16);
     }
     int cbpc = chroma_cbp_and_nnz(e, mb, lv);
-    e->mb_cbp[mb] = (uint8_t)((cbpc << 4) | (ac_flag ? 15 : 0));
-    e->mb_i16flags[mb] = 1;
+    e->mb_cbp[mb] = (uint8_t)((cbpc << 4) | (is_i4 ? (e->mb_cbp[mb] & 15) : 0));
+    e->mb_i16flags[mb] = 1; /* (an intra macroblock: what the in-loop filter's strengths ask) */
 }
 
 /* ---- P_L0_16x16 macroblock: MC prediction, transform, quant, recon ---- */
@@ -936,6 +1044,42 @@ static void write_mb_intra(orc_enc *e, bw_t *b, int mx, int my, int srow) {
     int mb = my * e->mbw + mx;
     const int16_t *lv = e->levels + (size_t)mb * ORC_MB_COEFS;
     int cbp = e->mb_cbp[mb], cbpc = cbp >> 4, acf = (cbp & 15) != 0;
+    if (e->mb_i4[mb]) {
+        /* I_NxN (7.3.5, 7.3.5.1): mb_type 0; per block prev_intra4x4_pred_mode_flag [+ rem_intra4x4_pred_mode] against
+         * predIntra4x4PredMode = min(mode of the block to the left, mode of the block above), DC when either macroblock is
+         * missing, a macroblock that is not Intra4x4 counting as DC (8.3.1.1); intra_chroma_pred_mode; coded_block_pattern
+         * me(v), Intra column; mb_qp_delta iff cbp != 0; the luma blocks of the 8x8s whose bit is set, 16 coefficients each */
+        bw_ue(b, 0);
+        const int8_t *own = e->mb_i4mode + (size_t)mb * 16;
+        for (int blk = 0; blk < 16; blk++) {
+            const int bx = orc_blk_x[blk], by = orc_blk_y[blk];
+            int mA, mB;
+            if (bx > 0) mA = own[orc_i4_idx(bx - 1, by)];
+            else if (mx > 0) mA = e->mb_i4[mb - 1] ? e->mb_i4mode[(size_t)(mb - 1) * 16 + orc_i4_idx(3, by)] : 2;
+            else mA = -1;
+            if (by > 0) mB = own[orc_i4_idx(bx, by - 1)];
+            else if (my > srow) mB = e->mb_i4[mb - e->mbw] ? e->mb_i4mode[(size_t)(mb - e->mbw) * 16 + orc_i4_idx(bx, 3)] : 2;
+            else mB = -1;
+            const int pm = orc_i4_pred_mode(mA, mB), m = own[blk];
+            if (m == pm)
+                bw_put(b, 1, 1);
+            else {
+                bw_put(b, 0, 1);
+                bw_put(b, (uint32_t)(m < pm ? m : m - 1), 3);
+            }
+        }
+        bw_ue(b, 0); /* intra_chroma_pred_mode = DC */
+        bw_ue(b, e->cbp_to_code_intra[cbp]);
+        if (cbp) bw_se(b, 0); /* mb_qp_delta */
+        for (int q = 0; q < 4; q++)
+            if (cbp & (1 << q))
+                for (int k = 0; k < 4; k++) {
+                    int blk = 4 * q + k;
+                    cavlc_block(b, lv + blk * 16, 16, luma_nc(e, mx, my, orc_blk_x[blk], orc_blk_y[blk], srow));
+                }
+        write_chroma_residual(e, b, mx, my, srow, lv, cbpc);
+        return;
+    }
     bw_ue(b, (uint32_t)(1 + e->mb_i16mode[my * e->mbw + mx] + 4 * cbpc + 12 * acf)); /* mb_type, table 7-11: Intra16x16PredMode 0 V, 1 H, 2 DC, 3 plane */
     bw_ue(b, 0);                                                   /* intra_chroma_pred_mode = DC */
     bw_se(b, 0);                                                   /* mb_qp_delta */

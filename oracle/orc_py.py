@@ -64,6 +64,8 @@ def lib():
         L.orc_dequant.argtypes = [C.c_int] * 3
         L.orc_me_rank.argtypes = [C.c_int] * 2
         L.orc_cavlc_block_bits.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_intra4_predict.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_intra4_topright_available.argtypes = [C.c_int] * 4
         L.orc_rc_qp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int]
         L.orc_enc_picture_qp.argtypes = [C.c_void_p]
         L.orc_escape.restype = C.c_size_t

@@ -49,6 +49,9 @@ static const uint8_t orc_chroma_qp[52] = {
 
 /* me(v): coded_block_pattern -> codeNum for Inter macroblocks, 4:2:0
  * (table 9-4, column "Inter").  Stored as codeNum -> cbp; inverted at init. */
+/* Table 9-4, column "Intra_4x4, Intra_8x8" (chroma_format_idc 1 or 2): codeNum -> coded_block_pattern */
+static const uint8_t orc_golomb_to_intra_cbp[48] = {47, 31, 15, 0,  23, 27, 29, 30, 7,  11, 13, 14, 39, 43, 45, 46, 16, 3,  5,  10, 12, 19, 21, 26,
+                                                    28, 35, 37, 42, 44, 1,  2,  4,  8,  17, 18, 20, 24, 6,  9,  22, 25, 32, 33, 34, 36, 40, 38, 41};
 static const uint8_t orc_golomb_to_inter_cbp[48] = {
     0,  16, 1,  2,  4,  8,  32, 3,  5,  10, 12, 15, 47, 7,  11, 13,
     14, 6,  9,  31, 35, 37, 42, 44, 33, 34, 36, 40, 39, 43, 45, 46,
