@@ -467,7 +467,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                            world, "halo (%d luma rows per edge)" % args.halo if args.halo else "whole-band", args.backend))
                        if slices_mode else ("1 stream per GPU, no collective" if world > 1 else "single GPU"),
                        "steps_pipelined": pipelined,
-                       "intra_modes": ["DC", "V/H/DC", "V/H/DC/plane"][args.intra_modes], "subpel": ["none", "half-sample", "quarter-sample"][args.subpel], "deblock": bool(args.deblock), "rate_control": ("crf %g" % args.crf) if args.crf is not None else "fixed QP",
+                       "intra_modes": ["DC", "V/H/DC", "V/H/DC/plane", "Intra4x4 | Intra16x16 V/H/DC/plane"][args.intra_modes], "subpel": ["none", "half-sample", "quarter-sample"][args.subpel], "deblock": bool(args.deblock), "rate_control": ("crf %g" % args.crf) if args.crf is not None else "fixed QP",
                        "bytes_per_step": bytes_per_step,
                        "bitstream_fnv1a": "%016x" % tally.fnv1a if tally else None,
                        "cpu_oracle_note": ORACLE_NOTE},
@@ -595,7 +595,7 @@ def main():
     ap.add_argument("--halo", type=int, default=16, help="slices mode: luma rows exchanged per band edge (0 = whole bands)")
     ap.add_argument("--deblock", action="store_true", help="in-loop deblocking filter inside every slice (spec/CODEC.md section 5a); default off: not a headline configuration")
     ap.add_argument("--subpel", type=int, default=0, choices=[0, 1, 2], help="sub-sample refinement of the motion vectors (spec/CODEC.md section 2a): 0 none (default, the definition the metric is quoted on), 1 half-sample, 2 half- then quarter-sample; not a headline configuration")
-    ap.add_argument("--intra-modes", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2], help="Intra16x16 prediction of I pictures: 0 DC only (default, the definition the metric's digests are frozen on), 1 vertical / horizontal / DC by SAD, 2 plane as well; not a headline configuration")
+    ap.add_argument("--intra-modes", type=int, nargs="?", const=1, default=0, choices=[0, 1, 2, 3], help="intra prediction of I pictures: 0 Intra16x16 DC only (default, the definition the metric's digests are frozen on), 1 vertical / horizontal / DC by SAD, 2 plane as well, 3 Intra4x4 tried against that (the C API's preset default); not a headline configuration")
     ap.add_argument("--crf", type=float, default=None, help="X264_RC_CRF with this rate factor instead of fixed QP (spec/CODEC.md section 1a); not a headline configuration")
     ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--control", default=None, choices=("nccl", "gloo"), help="torch.distributed backend of the control plane (barrier, max-over-ranks time, the RCCL id); default: --backend")

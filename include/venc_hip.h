@@ -48,7 +48,8 @@ typedef struct {
     int rc_mode;       /* 0: every picture at qp; 1: picture QP chosen on the GPU from the previous picture's motion search
                           (spec/CODEC.md section 1a: the frame-level approximation of libx264's CRF; qp = the rate factor,
                           IDR pictures qp - 3, P pictures qp +- up to 6).  Whole-picture engines only. */
-    int intra_modes;   /* 0: Intra16x16 with DC prediction only (the three-kernel I path); 2: as 1 plus plane prediction; 1: vertical / horizontal / DC chosen
+    int intra_modes;   /* 0: Intra16x16 with DC prediction only (the three-kernel I path); 3: as 2 plus Intra4x4 tried against the best 16x16 predictor
+                          (nine modes per block by SAD, spec/CODEC.md section 3); 2: as 1 plus plane prediction; 1: vertical / horizontal / DC chosen
                           per macroblock by SAD (spec/CODEC.md section 3; one wavefront kernel, ~3x the I-step time, hidden
                           behind the previous unit's P steps) */
     int deblock;       /* 0: no in-loop filter (disable_deblocking_filter_idc = 1); 1: H.264 8.7 inside every slice (idc 2,

@@ -29,8 +29,9 @@
  * to 12..51), not libx264's adaptive rate control.  Preset names select the
  * optional coding tools as libx264's do in spirit: every preset but "ultrafast"
  * switches on quarter-sample motion refinement (hip.i_subpel = 2), the in-loop
- * deblocking filter (hip.i_deblock = 1) and Intra16x16 V / H / DC / plane
- * prediction (hip.i_intra_modes = 2); "ultrafast" leaves them off.  Of the tunes
+ * deblocking filter (hip.i_deblock = 1) and, for I pictures, Intra16x16 V / H / DC /
+ * plane prediction with Intra4x4 tried against it (hip.i_intra_modes = 3);
+ * "ultrafast" leaves them off (Intra16x16 with plane prediction only).  Of the tunes
  * only "zerolatency" changes behaviour (no output delay).  Unknown names fail
  * (av_encode.c:384-386).
  */
@@ -115,8 +116,9 @@ typedef struct x264_param_t {
          * ncclAllGather).  pf_exchange, when set, takes precedence. */
         int i_rccl_world, i_rccl_rank, i_halo_rows;
         unsigned char rccl_id[128];
-        /* Intra16x16 prediction of I pictures: 2 (x264_param_default_preset's default, like libx264's presets) = vertical /
-         * horizontal / DC / plane chosen per macroblock by SAD; 1 = without plane; 0 = DC only (the codec definition of round 1, what bench.py measures) */
+        /* Intra prediction of I pictures: 3 (x264_param_default_preset's default, like libx264's presets) = Intra4x4 (nine modes per
+         * block) tried against the best Intra16x16 predictor; 2 = Intra16x16 vertical / horizontal / DC / plane chosen per macroblock by
+         * SAD ("ultrafast"); 1 = without plane; 0 = DC only (the codec definition of round 1, what bench.py measures) */
         int i_intra_modes;
         /* sub-sample refinement of the motion vectors (libx264's analyse.i_subpel_refine, which the reference leaves to its
          * preset, av_encode.c:365): 0 = integer-sample vectors (what bench.py measures), 1 = half-sample, 2 = half- then

@@ -28,12 +28,16 @@ CASES = [
     dict(name="cif_ippp", w=352, h=288, qp=26, slices=8, keyint=30, frames=5, seed=0x1234ABCD),
     dict(name="qcif_qp20_crop", w=178, h=146, qp=20, slices=3, keyint=3, frames=5, seed=77),
     dict(name="tiny_qp40", w=64, h=48, qp=40, slices=2, keyint=4, frames=6, seed=5),
+    # every optional coding tool the C API's presets switch on (round 3: with Intra4x4): rate control, Intra4x4 / Intra16x16 with
+    # plane prediction, quarter-sample vectors, in-loop filter
+    dict(name="cif_all_tools", w=352, h=288, qp=26, slices=4, keyint=4, frames=7, seed=0x1234ABCD,
+         tools=dict(rc=True, intra_modes=3, subpel=2, deblock=True)),
 ]
 
 
 def run(case):
     enc = orc_py.Encoder(case["w"], case["h"], qp=case["qp"], n_slices=case["slices"], keyint=case["keyint"],
-                         fps=(30, 1), sar=(1, 1))
+                         fps=(30, 1), sar=(1, 1), **case.get("tools", {}))
     out = dict(case)
     out["frames_sha256"], out["frame_bytes"] = [], []
     dump = {}

@@ -454,9 +454,9 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
     t = read_track(data)
     assert t["timescale"] == 24 and t["stts"] == [(n, 1)] and t["stss"] == [1, 4, 7] and (t["width"], t["height"]) == (w, h)
     # the C driver opens the encoder as the reference does: X264_RC_CRF (av_encode.c:400-401) = spec/CODEC.md section 1a
-    # ... and with the preset's intra modes (x264_param_default_preset: Intra16x16 V / H / DC)
+    # ... and with the preset's intra modes (x264_param_default_preset: Intra4x4 tried against Intra16x16 V / H / DC / plane)
     # ... and its sub-sample refinement (every preset but ultrafast: half- then quarter-sample stage)
-    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=2, subpel=2, deblock=True)
+    enc = orc.Encoder(w, h, qp=27, n_slices=slices, keyint=keyint, fps=(24, 1), sar=(1, 1), threads=4, rc=True, intra_modes=3, subpel=2, deblock=True)
     dec = orc.Decoder()
     got = samples_of(data, t)
     for k, f in enumerate(frames):
@@ -606,7 +606,7 @@ def test_av_encode_reference_command_line_and_progress_line(venc, orc, tmp_path)
     assert pct == sorted(pct) and pct[-1] <= 100.0 and pct[-1] > 50.0
     t = read_track(open(mp4, "rb").read())
     assert len(t["stsz"]) == 9 and t["stss"] == [1, 6] and t["timescale"] == 25
-    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=2, subpel=2, deblock=True)
+    enc = orc.Encoder(w, h, qp=27, n_slices=3, keyint=5, fps=(25, 1), sar=(1, 1), threads=4, rc=True, intra_modes=3, subpel=2, deblock=True)
     got = samples_of(open(mp4, "rb").read(), t)
     for k in range(9):
         ref = enc.encode(*frames[k])
@@ -747,6 +747,64 @@ def test_intra16x16_plane_prediction_matches_oracle(venc, orc, w, h, qp, slices)
         modes |= set(int(x) for x in (eng.debug(2)[:, 25] >> 1) & 3)
     assert 3 in modes, modes
     eng.close()
+
+
+@pytest.mark.parametrize("w,h,qp,slices,n", [
+    (16, 16, 24, 1, 2),          # one macroblock: no neighbour at all
+    (64, 48, 30, 2, 3),
+    (352, 288, 26, 4, 3),
+    (178, 146, 30, 3, 3),        # clamped ingest, ragged macroblocks
+    (176, 464, 28, 1, 2),        # 29 macroblock rows in one slice: the second chunk reads its top row (and the four samples beyond) from memory
+    (1920, 1080, 26, 8, 2),
+    (352, 288, 44, 1, 2),        # coarse quantiser: most blocks empty, cbp bits per 8x8
+])
+def test_intra4x4_matches_oracle(venc, orc, w, h, qp, slices, n):
+    """Intra4x4 tried against the best Intra16x16 predictor (intra_modes = 3, spec/CODEC.md section 3):
+    the engine's k_intra_modes<true> -- sixteen blocks per macroblock in decoding order, nine predictors each, rows two macroblocks
+    apart because block 5 predicts from the macroblock above-right -- against the oracle, stage by stage: levels, reconstruction,
+    slice RBSPs (I_NxN syntax: the modes against their predictions, the Intra column of table 9-4); all-I.  Conformance of the tool
+    itself is UNPINNED (tests/test_oracle_intra4.py says what pins the oracle's predictors)."""
+    enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=1, threads=8, intra_modes=3)
+    eng = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2, intra_modes=3)
+    kinds = set()
+    for t, (y, u, v) in enumerate(_stripes_and_texture(venc, w, h, n)):
+        ref = enc.encode(y, u, v)
+        eng.upload(t % 2, y, u, v)
+        eng.encode_step([t % 2], [t % 2], True, 0, [t & 1])
+        eng.sync()
+        flags = eng.debug(2)[:, 25]
+        rec_o = enc.recon()
+        if not np.array_equal(eng.debug(4), rec_o[0]):
+            bad = np.argwhere(eng.debug(4) != rec_o[0])
+            raise AssertionError("luma recon frame %d: first mismatch at (y, x) = %s, macroblock %d (flags %d), %d samples differ" % (
+                t, bad[0], (bad[0][0] // 16) * ((w + 15) // 16) + bad[0][1] // 16, flags[(bad[0][0] // 16) * ((w + 15) // 16) + bad[0][1] // 16], len(bad)))
+        lv_g, lv_o = eng.debug(1), enc.levels()
+        if not np.array_equal(lv_g, lv_o):
+            bad = np.argwhere(lv_g != lv_o)
+            raise AssertionError("levels frame %d: first mismatch mb,blk,idx=%s gpu=%d orc=%d (%d diffs)" % (
+                t, bad[0], lv_g[tuple(bad[0])], lv_o[tuple(bad[0])], len(bad)))
+        for p in (1, 2):
+            assert np.array_equal(eng.debug(4 + p), rec_o[p]), "recon plane %d frame %d" % (p, t)
+        sl_o = [unescape(b) for (ty, _, b) in split_nals(ref.data) if ty in (1, 5)]
+        assert eng.get_slices(t % 2) == sl_o, "slices frame %d" % t
+        kinds |= set(int(x) & 8 for x in flags)
+    if w >= 176 and h >= 144 and qp < 40:
+        assert kinds == {0, 8}, kinds     # both macroblock types were chosen somewhere
+    eng.close()
+
+
+def test_x264_api_with_every_preset_tool_matches_oracle(venc, orc):
+    """What a caller of the C API gets with the preset's defaults (every preset but ultrafast): CRF, Intra4x4 / Intra16x16 with plane,
+    quarter-sample vectors, the in-loop filter -- through x264_encoder_encode, GOP-batched, against the oracle frame by frame."""
+    w, h, n, keyint = 352, 288, 14, 5
+    frames = [venc.synth_frame(w, h, t, 3) for t in range(n)]
+    got = _x264_stream(venc, frames, w, h, slices=3, keyint=keyint, fps=(30, 1), sar=(1, 1), crf=24, gop_batch=2, intra_modes=3, subpel=2, deblock=True)
+    enc = orc.Encoder(w, h, qp=24, n_slices=3, keyint=keyint, fps=(30, 1), sar=(1, 1), threads=8, rc=True, intra_modes=3, subpel=2, deblock=True)
+    dec = orc.Decoder()
+    for t, f in enumerate(frames):
+        ref = enc.encode(*f)
+        assert got[t].payload == ref.data, "frame %d" % t
+        assert dec.decode(got[t].payload) == 1 and np.array_equal(dec.planes()[0], enc.recon()[0])
 
 
 def test_x264_api_with_intra_modes_and_rate_control(venc, orc):

@@ -86,7 +86,7 @@ static bool enc_x264_open(int width, int height, int fps_num, int fps_den, int s
     params.i_keyint_max = keyint;
     params.hip.i_gop_batch = gop_batch;
     /* the preset's coding tools can be pinned for measurements: VENC_SUBPEL=0/1/2 (sub-sample refinement; preset default 2,
-     * ultrafast 0), VENC_INTRA_MODES=0/1/2 (Intra16x16 DC only / V, H, DC / plane as well; preset default 2, ultrafast 0),
+     * ultrafast 0), VENC_INTRA_MODES=0/1/2/3 (Intra16x16 DC only / V, H, DC / plane as well / Intra4x4 tried against that; preset default 3, ultrafast 2),
      * VENC_DEBLOCK=0/1 (in-loop filter; preset default 1, ultrafast 0) */
     if (getenv("VENC_SUBPEL")) params.hip.i_subpel = atoi(getenv("VENC_SUBPEL"));
     if (getenv("VENC_INTRA_MODES")) params.hip.i_intra_modes = atoi(getenv("VENC_INTRA_MODES"));

@@ -917,7 +917,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         if (c->cfg.intra_modes) {
             /* Intra16x16 vertical / horizontal / DC by SAD: the plain dependency wavefront (venc_intra2.hip k_intra_modes) */
             const venc_geom &gi = c->cfg.rc_mode ? c->g_idr : g;
-            hipLaunchKernelGGL(k_intra_modes, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, gi, b, S);
+            if (c->cfg.intra_modes >= 3)
+                hipLaunchKernelGGL(k_intra_modes<true>, dim3(band_slices, 1, n_items), dim3(64 * (c->intra_waves < INTRA4_MAX_WAVES ? c->intra_waves : INTRA4_MAX_WAVES)), 0, s1, gi, b, S);
+            else
+                hipLaunchKernelGGL(k_intra_modes<false>, dim3(band_slices, 1, n_items), dim3(64 * c->intra_waves), 0, s1, gi, b, S);
         } else {
             /* DC prediction only: transform off the dependency chain, DC chain, reconstruction (venc_intra2.hip) */
             const venc_geom &gi = c->cfg.rc_mode ? c->g_idr : g; /* IDR pictures under rate control: their own quantiser constants */
@@ -1443,7 +1446,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         static const int blk_raster[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
         for (size_t m = 0; m < nmb; m++) {
             int16_t *r = lv + m * VENC_MB_COEFS;
-            const int i16 = mi[m].flags & 1, cbpc = mi[m].cbpc;
+            const int i16 = (mi[m].flags & 1) && !(mi[m].flags & 8), cbpc = mi[m].cbpc; /* (Intra4x4: slot 16 holds the modes, not levels) */
             for (int b = 0; b < 16; b++)
                 if (mi[m].nnz[blk_raster[b]] == 0) memset(r + b * 16, 0, 32);
             if (!i16) memset(r + 16 * 16, 0, 32);

@@ -34,7 +34,7 @@
 typedef struct {
     uint8_t nnz[24];
     uint8_t cbp;   /* coded_block_pattern, luma part: bits 0-3 = the four 8x8 blocks */
-    uint8_t flags; /* bit 0: Intra16x16 */
+    uint8_t flags; /* bit 0: intra (Intra16x16 unless bit 3); bits 1-2: Intra16x16PredMode; bit 3: Intra4x4 (its sixteen modes sit in level slot 16) */
     uint8_t cbpc;  /* coded_block_pattern, chroma part (0, 1, 2): its own byte, the luma and chroma transform
                       blocks of a step run side by side and must not share one */
     uint8_t pad[5];

@@ -393,6 +393,169 @@ __global__ __launch_bounds__(256) void k_intra_rec(venc_geom g, venc_bufs B, ven
     }
 }
 
+/* ================================================================== Intra4x4 (spec/CODEC.md section 3, intra_modes = 3; H.264 8.3.1)
+ * The trial of a macroblock as sixteen 4x4 blocks in decoding order, run by the 16 luma lanes of the macroblock's half-wave
+ * with lane = SAMPLE of the block at hand (x = lane & 3, y = lane >> 2) -- the blocks are a serial chain (each predicts from
+ * the reconstruction of the ones before it), so the parallelism is inside a block.  Per block:
+ *   edge      the 13 neighbouring samples as one vector E' across the lanes: E'[0] = E'[1] = L3, L2, L1, L0, corner, T0 .. T7,
+ *             E'[14] = T7 (the doubled ends make p[-1,3] and p[7,-1] repeat where 8.3.1.2.4 / .9 weight them by 3); lane i
+ *             also forms F3[i] = (E'[i-1] + 2 E'[i] + E'[i+1] + 2) >> 2 and A2[i] = (E'[i] + E'[i+1] + 1) >> 1
+ *   predict   every directional predictor of every sample is ONE of those 45 numbers (i4_tab: which, per mode and sample):
+ *             a lane fetches its eight with wave shuffles; DC from the sums of T0..T3 and L0..L3
+ *   choose    SAD of each usable mode over the 16 lanes, smallest wins, smaller mode number on ties
+ *   code      residual, 4x4 transform (each lane one coefficient: shuffles along its row, then its column), quantisation of
+ *             all 16 coefficients with the intra rounding, dequantisation, inverse transform, reconstruction into the tile
+ * The tile (LDS, one per half-wave) holds the macroblock's reconstruction with the row above (and four samples beyond),
+ * the column to the left and the corner, its source samples, the levels and counts of the trial. */
+#define INTRA4_MAX_WAVES 8 /* waves per block of k_intra_modes<true>: 512 threads leave it 256 registers (at 1024 threads and 128 the trial spilled 90) */
+struct i4_tile {
+    uint32_t lv[16 * 8];  /* [block, luma4x4BlkIdx][16 levels in scan order, int16 pairs] */
+    uint32_t src[16 * 4]; /* source samples, row y at bytes 16 y .. */
+    uint32_t rec[17 * 6]; /* reconstruction: row r = -1 .. 15 at byte (r + 1) * 24, column c = -4 .. 19 at byte 4 + c */
+    uint32_t nz[4];       /* bytes: non-zero levels of each block */
+    uint32_t mode[4];     /* bytes: Intra4x4PredMode of each block */
+    uint32_t pad[2];
+};
+#define I4_RS 24 /* bytes per row of i4_tile.rec */
+
+/* (kind << 4) | index into E': kind 0 = E', 1 = F3, 2 = A2.  Mode m, sample (x, y); 8.3.1.2.1 - 8.3.1.2.9 with
+ * P(x, -1) = E'[6 + x], P(-1, y) = E'[4 - y], P(-1, -1) = E'[5] */
+DEVFN int i4_tab(int m, int x, int y) {
+    switch (m) {
+        case 0: return 6 + x;
+        case 1: return 4 - y;
+        case 3: return (1 << 4) | (7 + x + y);
+        case 4: return (1 << 4) | (5 + x - y);
+        case 5: {
+            const int j = x - (y >> 1), z = 2 * x - y;
+            if (z >= 0 && !(z & 1)) return (2 << 4) | (5 + j);
+            if (z >= -1) return (1 << 4) | (5 + j);
+            return (1 << 4) | (6 - y);
+        }
+        case 6: {
+            const int j = y - (x >> 1), z = 2 * y - x;
+            if (z >= 0 && !(z & 1)) return (2 << 4) | (4 - j);
+            if (z >= -1) return (1 << 4) | (5 - j);
+            return (1 << 4) | (4 + x);
+        }
+        case 7: {
+            const int j = x + (y >> 1);
+            return !(y & 1) ? (2 << 4) | (6 + j) : (1 << 4) | (7 + j);
+        }
+        case 8: {
+            const int j = y + (x >> 1), z = x + 2 * y;
+            if (z > 5) return 1;
+            if (z == 5) return (1 << 4) | 1;
+            return !(z & 1) ? (2 << 4) | (3 - j) : (1 << 4) | (3 - j);
+        }
+    }
+    return 0;
+}
+
+/* one pass of the inverse transform's butterfly for the lane at position t (0 .. 3) of its row / column: inputs a b c d
+ * in position order (8.5.12.2: e0 = a + c, e1 = a - c, e2 = (b >> 1) - d, e3 = b + (d >> 1); f = e0 + e3, e1 + e2, e1 - e2, e0 - e3) */
+DEVFN int i4_inv1d(int t, int a, int b, int c, int d) {
+    const int bb = (t == 1 || t == 2) ? b >> 1 : b, dd = (t == 0 || t == 3) ? d >> 1 : d;
+    const int tb = t < 2 ? bb : -bb, tc = (t == 0 || t == 3) ? c : -c, td = (t & 1) ? -dd : dd;
+    return a + tb + tc + td;
+}
+DEVFN int i4_fwd1d(int t, int a, int b, int c, int d) { /* Cf = [1 1 1 1; 2 1 -1 -2; 1 -1 -1 1; 1 -2 2 -1] */
+    return t == 0 ? a + b + c + d : t == 1 ? 2 * a + b - c - 2 * d : t == 2 ? a - b - c + d : a - 2 * b + 2 * c - d;
+}
+
+/* The trial.  Called by all lanes of the macroblock's half-wave (l32 = lane & 31; lanes 16 .. 31 only ride along); the
+ * tile's row -1 / column -1 / corner and its source samples are in place.  aL, aT, aTR: the macroblock to the left, above,
+ * above-right is in the slice (the one above-left is iff both aL and aT).  Returns the sum of the sixteen blocks' SADs
+ * (the same in every lane of the half); reconstruction, levels, counts and modes are left in the tile. */
+DEVFN uint32_t i4_trial(i4_tile &T, const venc_qparams &q, int lane, bool aL, bool aT, bool aTR) {
+    const int l32 = lane & 31, hbase = lane & 32, p = l32 & 15, x = p & 3, y = p >> 2;
+    const bool px = l32 < 16;
+    uint8_t *const rec = (uint8_t *)T.rec;
+    const uint8_t *const src = (const uint8_t *)T.src;
+    /* where this lane's entry of E' sits relative to the block's top-left sample: lanes 0, 1 L3; 2 L2; 3 L1; 4 L0; 5 the corner;
+     * 6 .. 13 T0 .. T7; 14, 15 T7 */
+    const int e_row = p <= 4 ? (p == 0 ? 3 : 4 - p) : -1;
+    const int e_col = p <= 5 ? -1 : min(p - 6, 7);
+    int tab[9];
+#pragma unroll
+    for (int m = 0; m < 9; m++) tab[m] = i4_tab(m, x, y);
+    const int cls = venc_pos_class(p);
+    const int mf = q.mf[cls], vv = q.v[cls] << q.per;
+    int scan = 0; /* scan position of this lane's coefficient (raster p) */
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        if (venc_zigzag_ct(i) == p) scan = i;
+    uint32_t total = 0;
+    for (int k = 0; k < 16; k++) {
+        const int bx = blk_x(k), by = blk_y(k);
+        const bool top = by > 0 || aT, left = bx > 0 || aL;
+        const bool corner = (bx > 0 && by > 0) || (bx == 0 && by > 0 && aL) || (bx > 0 && by == 0 && aT) || (bx == 0 && by == 0 && aL && aT);
+        const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (bx < 3 && blk_of(bx + 1, by - 1) < k);
+        uint8_t *const o = rec + (4 * by + 1) * I4_RS + 4 + 4 * bx; /* the block's top-left sample in the tile */
+        /* ---- the edge vector and the three numbers per lane ---- */
+        const int ec = (!topright && e_col > 3) ? 3 : e_col;
+        const uint32_t e = o[e_row * I4_RS + ec];
+        const uint32_t ep = (uint32_t)__shfl((int)e, hbase | ((p + 15) & 15)), en = (uint32_t)__shfl((int)e, hbase | ((p + 1) & 15));
+        const uint32_t pk = e | (((ep + 2u * e + en + 2u) >> 2) << 8) | (((e + en + 1u) >> 1) << 16);
+        /* ---- the nine predictors of this lane's sample ---- */
+        int pm[9];
+#pragma unroll
+        for (int m = 0; m < 9; m++) {
+            if (m == 2) continue;
+            const uint32_t v = (uint32_t)__shfl((int)pk, hbase | (tab[m] & 15));
+            pm[m] = (int)((v >> (8 * (tab[m] >> 4))) & 255u);
+        }
+        {
+            const uint32_t part = ((p >= 6 && p <= 9) ? e : 0u) | ((p >= 1 && p <= 4) ? e << 16 : 0u);
+            const uint32_t sums = half_sum32(px ? part : 0u, lane);
+            const int sT = (int)(sums & 0xffffu), sL = (int)(sums >> 16);
+            pm[2] = (top && left) ? (sT + sL + 4) >> 3 : left ? (sL + 2) >> 2 : top ? (sT + 2) >> 2 : 128;
+        }
+        /* ---- SADs, the choice ---- */
+        const int sv = (int)src[(4 * by + y) * 16 + 4 * bx + x];
+        uint32_t d[9];
+#pragma unroll
+        for (int m = 0; m < 9; m++) d[m] = px ? (uint32_t)abs(sv - pm[m]) : 0u;
+        const uint32_t s01 = half_sum32(d[0] | (d[1] << 16), lane), s23 = half_sum32(d[2] | (d[3] << 16), lane);
+        const uint32_t s45 = half_sum32(d[4] | (d[5] << 16), lane), s67 = half_sum32(d[6] | (d[7] << 16), lane);
+        const uint32_t s8 = half_sum32(d[8], lane);
+        const bool tlc = top && left && corner;
+        const uint32_t sad[9] = {top ? s01 & 0xffffu : 0xffffu, left ? s01 >> 16 : 0xffffu, s23 & 0xffffu, top ? s23 >> 16 : 0xffffu,
+                                 tlc ? s45 & 0xffffu : 0xffffu, tlc ? s45 >> 16 : 0xffffu, tlc ? s67 & 0xffffu : 0xffffu,
+                                 top ? s67 >> 16 : 0xffffu, left ? s8 : 0xffffu};
+        uint32_t best = sad[0];
+        int bm = 0, pred = pm[0];
+#pragma unroll
+        for (int m = 1; m < 9; m++)
+            if (sad[m] < best) best = sad[m], bm = m, pred = pm[m];
+        total += best;
+        /* ---- residual -> coefficient of this lane (row pass, then column pass) ---- */
+        const int r0 = sv - pred;
+        const int ra = __shfl(r0, hbase | (4 * y)), rb = __shfl(r0, hbase | (4 * y + 1)), rc = __shfl(r0, hbase | (4 * y + 2)), rd = __shfl(r0, hbase | (4 * y + 3));
+        const int h1 = i4_fwd1d(x, ra, rb, rc, rd);
+        const int ca = __shfl(h1, hbase | x), cb = __shfl(h1, hbase | (4 + x)), cc = __shfl(h1, hbase | (8 + x)), cd = __shfl(h1, hbase | (12 + x));
+        const int w = i4_fwd1d(y, ca, cb, cc, cd);
+        const int lvl = venc_quant_mag(w, mf, q.f_intra, q.qbits);
+        const uint32_t nzb = (uint32_t)(__ballot(px && lvl != 0) >> hbase) & 0xffffu;
+        if (px) ((int16_t *)T.lv)[k * 16 + scan] = (int16_t)lvl;
+        /* ---- back: dequantisation, inverse transform (rows first, 8.5.12.2), reconstruction ---- */
+        const int dq = VENC_MUL24(lvl, vv);
+        const int ia = __shfl(dq, hbase | (4 * y)), ib = __shfl(dq, hbase | (4 * y + 1)), ic = __shfl(dq, hbase | (4 * y + 2)), id = __shfl(dq, hbase | (4 * y + 3));
+        const int f1 = i4_inv1d(x, ia, ib, ic, id);
+        const int ja = __shfl(f1, hbase | x), jb = __shfl(f1, hbase | (4 + x)), jc = __shfl(f1, hbase | (8 + x)), jd = __shfl(f1, hbase | (12 + x));
+        const int rr = (i4_inv1d(y, ja, jb, jc, jd) + 32) >> 6;
+        if (px) {
+            o[y * I4_RS + x] = (uint8_t)venc_clip_u8(pred + rr);
+            if (p == 0) {
+                ((uint8_t *)T.nz)[k] = (uint8_t)__popc(nzb);
+                ((uint8_t *)T.mode)[k] = (uint8_t)bm;
+            }
+        }
+        /* (the next block reads the tile: LDS operations of a wave are ordered) */
+    }
+    return total;
+}
+
 /* ================================================================== k_intra_modes
  * I pictures with Intra16x16 prediction chosen per macroblock among vertical (0), horizontal (1) and DC (2) by the SAD of
  * the predictor against the source (spec/CODEC.md section 3: smallest SAD, the smaller mode number on ties; vertical
@@ -404,8 +567,13 @@ __global__ __launch_bounds__(256) void k_intra_rec(venc_geom g, venc_bufs B, ven
  * through a small LDS ring (16 luma + 8 + 8 chroma samples), its right COLUMN handed on in registers.  ~4.5 us per
  * wavefront step against 0.9 for the DC-only chain -- affordable because intra steps run ahead of their unit on a
  * stream of their own (venc_hip.hip, INTRA AHEAD): at 1080p the ~0.6 ms of an I step hide behind six P steps. */
-__global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, venc_step S) {
+/* I4: Intra4x4 is tried against the best 16x16 predictor (intra_modes = 3).  Its block 5 predicts from the macroblock
+ * above-RIGHT, so a row then runs TWO macroblocks behind the row above (one otherwise). */
+template <bool I4>
+__global__ __launch_bounds__(I4 ? 64 * INTRA4_MAX_WAVES : 1024) void k_intra_modes(venc_geom g, venc_bufs B, venc_step S) {
     __shared__ uint32_t s_bot[2 * INTRA_MAX_WAVES][4][8]; /* per macroblock row, ring of 4: bottom row Y[16] Cb[8] Cr[8] */
+    __shared__ __attribute__((aligned(16))) i4_tile s_i4[I4 ? 2 * INTRA_MAX_WAVES : 1];
+    constexpr int SKEW = I4 ? 2 : 1;
     const int item = blockIdx.z, s = S.slice0 + blockIdx.x, tid = threadIdx.x;
     const int nw = blockDim.x >> 6;
     const int wv = tid >> 6, lane = tid & 63, l32 = lane & 31, hbase = lane & 32;
@@ -423,7 +591,7 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
     for (int cb = r0; cb < r1; cb += 2 * nw) {
         const int nr = min(2 * nw, r1 - cb);
         const int my = cb + rw;
-        const int steps = g.mbw + nr - 1;
+        const int steps = g.mbw + SKEW * (nr - 1);
         uint32_t left4 = 0;                      /* luma lanes: the four samples left of this lane's block rows */
         uint32_t lcol[4] = {0, 0, 0, 0};         /* plane prediction: the whole column left of the macroblock, and the corner sample */
         uint32_t corner = 0;
@@ -433,7 +601,7 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
         uint32_t cq[4] = {0, 0, 0, 0};
         if (rw < nr) load_cur_rows(cur, cstride, pw, ph, bx, pyl, cur_al, cq);
         for (int step = 0; step < steps; step++) {
-            const int mx = step - rw;
+            const int mx = step - SKEW * rw;
             if (rw < nr && mx >= 0 && mx < g.mbw) {
                 uint32_t nq[4] = {0, 0, 0, 0};
                 if (mx + 1 < g.mbw) load_cur_rows(cur, cstride, pw, ph, (luma ? (mx + 1) * 16 : (mx + 1) * 8) + bx, pyl, cur_al, nq);
@@ -441,10 +609,13 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                 const bool aL = mx > 0, aT = my > r0;
                 /* the row above: 8 dwords Y0..Y3 Cb0 Cb1 Cr0 Cr1 */
                 uint32_t tb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t tr4 = 0; /* (I4) the first four samples of the row above the macroblock to the right */
+                const bool aTR = aT && mx + 1 < g.mbw;
                 if (aT) {
                     if (rw > 0) {
                         const uint4 a = *(const uint4 *)&s_bot[rw - 1][mx & 3][0], c4 = *(const uint4 *)&s_bot[rw - 1][mx & 3][4];
                         tb[0] = a.x, tb[1] = a.y, tb[2] = a.z, tb[3] = a.w, tb[4] = c4.x, tb[5] = c4.y, tb[6] = c4.z, tb[7] = c4.w;
+                        if (I4 && aTR) tr4 = s_bot[rw - 1][(mx + 1) & 3][0];
                     } else {
                         /* the row above belongs to the previous chunk of this slice: its bottom lines come from memory */
                         int ys, us;
@@ -452,6 +623,7 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                         const uint8_t *ru = rec_plane(B, g, S.parity, item, 1, us) + (size_t)(my * 8 - 1) * us + mx * 8;
                         const uint8_t *rv = rec_plane(B, g, S.parity, item, 2, us) + (size_t)(my * 8 - 1) * us + mx * 8;
                         const uint4 a = *(const uint4 *)ry;
+                        if (I4 && aTR) tr4 = *(const uint32_t *)(ry + 16);
                         const uint2 cu = *(const uint2 *)ru, cv = *(const uint2 *)rv;
                         tb[0] = a.x, tb[1] = a.y, tb[2] = a.z, tb[3] = a.w, tb[4] = cu.x, tb[5] = cu.y, tb[6] = cv.x, tb[7] = cv.y;
                     }
@@ -514,11 +686,25 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                 }
                 sV = half_sum32(sV, lane), sH = half_sum32(sH, lane), sD = half_sum32(sD, lane);
                 int mode = 2;
-                {
-                    uint32_t best = sD;
-                    if (aL && sH <= best) best = sH, mode = 1;
-                    if (aT && sV <= best) best = sV, mode = 0;
-                    if (try_plane && sP < best) best = sP, mode = 3; /* (ties go to the smaller mode number) */
+                uint32_t best = sD;
+                if (aL && sH <= best) best = sH, mode = 1;
+                if (aT && sV <= best) best = sV, mode = 0;
+                if (try_plane && sP < best) best = sP, mode = 3; /* (ties go to the smaller mode number) */
+                /* Intra4x4 against it: the trial runs in the half-wave's tile; it wins iff its blocks' SADs sum to strictly less */
+                bool use_i4 = false;
+                i4_tile &T4 = s_i4[I4 ? (tid >> 5) : 0];
+                if (I4) {
+                    uint8_t *tr = (uint8_t *)T4.rec;
+                    if (l32 < 4) T4.rec[1 + l32] = tb[l32];
+                    if (l32 == 4) T4.rec[5] = tr4;
+                    if (l32 == 5) tr[3] = (uint8_t)corner;
+                    if (luma) {
+                        tr[(l32 + 1) * I4_RS + 3] = (uint8_t)((lcol[l32 >> 2] >> (8 * (l32 & 3))) & 255u);
+#pragma unroll
+                        for (int y = 0; y < 4; y++) T4.src[(by + y) * 4 + (bx >> 2)] = cq[y];
+                    }
+                    const uint32_t tot4 = i4_trial(T4, g.ql, lane, aL, aT, aTR);
+                    use_i4 = tot4 < best;
                 }
                 const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
                 int c[16], p[16];
@@ -533,11 +719,27 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                 for (int y = 0; y < 4; y++) cq[y] = nq[y];
                 mb_lane_out o;
                 mb_code<true, true>(lane, c, p, g, o);
+                if (I4 && use_i4 && luma) { /* the trial's results take the place of the 16x16 coding's (chroma is the same either way) */
+                    o.nnz = (int)((const uint8_t *)T4.nz)[l32];
+                    o.dclv = 0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const uint32_t wd = T4.lv[l32 * 8 + i];
+                        o.lv[2 * i] = (int)(int16_t)(wd & 0xffffu), o.lv[2 * i + 1] = (int)(int16_t)(wd >> 16);
+                    }
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        const uint32_t wd = T4.rec[(by + y + 1) * 6 + 1 + (bx >> 2)];
+                        o.rec[4 * y] = (int)(wd & 255u), o.rec[4 * y + 1] = (int)((wd >> 8) & 255u), o.rec[4 * y + 2] = (int)((wd >> 16) & 255u), o.rec[4 * y + 3] = (int)(wd >> 24);
+                    }
+                }
 
                 int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
                 venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
                 mb_store(l32, true, o, lv_mb, info, rec, wstride, px, py);
-                if (luma) { /* luma DC record (slot 16, zig-zag order) */
+                if (I4 && use_i4) { /* slot 16 holds no DC block: the sixteen Intra4x4PredModes, by luma4x4BlkIdx, for the entropy coder */
+                    if (luma) lv_mb[16 * 16 + l32] = (int16_t)((const uint8_t *)T4.mode)[l32];
+                } else if (luma) { /* luma DC record (slot 16, zig-zag order) */
                     const int rp = blk_y(l32) * 4 + blk_x(l32);
                     int zi = 0;
 #pragma unroll
@@ -553,9 +755,11 @@ __global__ __launch_bounds__(1024) void k_intra_modes(venc_geom g, venc_bufs B, 
                 }
                 const uint32_t hnz = (uint32_t)(__ballot(o.nnz > 0) >> hbase), hdc = (uint32_t)(__ballot(o.dclv != 0) >> hbase);
                 if (l32 == 0) {
-                    info->cbp = (uint8_t)((hnz & 0xffffu) ? 15 : 0);
+                    int cbpl = (hnz & 0xffffu) ? 15 : 0;
+                    if (I4 && use_i4) cbpl = ((hnz & 0xfu) ? 1 : 0) | ((hnz & 0xf0u) ? 2 : 0) | ((hnz & 0xf00u) ? 4 : 0) | ((hnz & 0xf000u) ? 8 : 0); /* (lane = luma4x4BlkIdx: four lanes per 8x8) */
+                    info->cbp = (uint8_t)cbpl;
                     info->cbpc = (uint8_t)(((hnz >> 16) & 0xffu) ? 2 : ((hdc >> 16) & 0xffu) ? 1 : 0);
-                    info->flags = (uint8_t)(1 | (mode << 1)); /* bit 0: Intra16x16; bits 1-2: Intra16x16PredMode */
+                    info->flags = (uint8_t)((I4 && use_i4) ? (1 | 8) : (1 | (mode << 1))); /* bit 0: intra; bits 1-2: Intra16x16PredMode; bit 3: Intra4x4 */
                     B.mvsad[(size_t)item * g.nmb + mb] = 0;
                 }
                 /* reconstructed edges for the neighbours: bottom row to the ring, right column to the next step */

@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         if (tid + 256 * k < VENC_TAB_SIZE) s_tab[tid + 256 * k] = tv[k];
     __syncthreads();
     const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
-    const bool i16 = (o1.z >> 8) & 1u;
+    const bool i4 = (o1.z >> 11) & 1u;              /* flags bit 3: Intra4x4 (I_NxN) */
+    const bool i16 = ((o1.z >> 8) & 1u) && !i4;     /* flags bit 0: intra */
 
     /* role decode */
     int slot = 0, first = 0, maxc = 16, nC = 0;
@@ -498,6 +499,35 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
             venc_bs_ue(&bs, (uint32_t)(1 + (int)((o1.z >> 9) & 3u) + 4 * cbpc + 12 * (cbpl != 0))); /* mb_type (table 7-11) carries Intra16x16PredMode: flags bits 1-2 */
             venc_bs_ue(&bs, 0);
             venc_bs_se(&bs, 0);
+        } else if (i4) {
+            /* I_NxN (7.3.5, 7.3.5.1): mb_type 0, sixteen prev_intra4x4_pred_mode_flag [+ rem_intra4x4_pred_mode] against
+             * min(mode of the block to the left, mode of the block above) -- DC when either macroblock is outside the slice, a
+             * macroblock that is not Intra4x4 counting as DC (8.3.1.1) --, intra_chroma_pred_mode, coded_block_pattern (Intra
+             * column of table 9-4), mb_qp_delta iff cbp != 0.  The modes sit in level slot 16 of their macroblock. */
+            const int16_t *lvb = B.levels + (size_t)item * g.nmb * VENC_MB_COEFS + 16 * 16;
+            __attribute__((aligned(16))) int16_t own[16], lm[16], tm[16];
+            const bool li4 = aL && ((l1.z >> 11) & 1u), ti4 = aT && ((t1.z >> 11) & 1u);
+#pragma unroll
+            for (int h2 = 0; h2 < 2; h2++) {
+                *(uint4 *)(own + 8 * h2) = ((const uint4 *)(lvb + (size_t)mb * VENC_MB_COEFS))[h2];
+                *(uint4 *)(lm + 8 * h2) = ((const uint4 *)(lvb + (size_t)(li4 ? mb - 1 : mb) * VENC_MB_COEFS))[h2];
+                *(uint4 *)(tm + 8 * h2) = ((const uint4 *)(lvb + (size_t)(ti4 ? mb - g.mbw : mb) * VENC_MB_COEFS))[h2];
+            }
+            venc_bs_ue(&bs, 0);
+#pragma unroll
+            for (int blk = 0; blk < 16; blk++) {
+                const int bx = blk_x(blk), by = blk_y(blk);
+                const int mA = bx > 0 ? own[blk_of(bx - 1, by)] : !aL ? -1 : li4 ? lm[blk_of(3, by)] : 2;
+                const int mB = by > 0 ? own[blk_of(bx, by - 1)] : !aT ? -1 : ti4 ? tm[blk_of(bx, 3)] : 2;
+                const int pm = (mA < 0 || mB < 0) ? 2 : min(mA, mB), m = own[blk];
+                if (m == pm)
+                    venc_bs_put(&bs, 1u, 1);
+                else
+                    venc_bs_put(&bs, (uint32_t)(m < pm ? m : m - 1), 4); /* flag 0 + three bits */
+            }
+            venc_bs_ue(&bs, 0);
+            venc_bs_ue(&bs, venc_cbp_intra_code[cbp]);
+            if (cbp) venc_bs_se(&bs, 0);
         } else {
             emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp, 0u); /* (P pictures are coded by k_cavlc_p) */
         }

@@ -122,7 +122,7 @@ int x264_param_default_preset(x264_param_t *param, const char *preset, const cha
     param->rc.f_rf_constant = 23.0f;
     param->hip.i_device = 0;
     param->hip.i_gop_batch = 1;
-    param->hip.i_intra_modes = 2;
+    param->hip.i_intra_modes = preset && strcmp(preset, "ultrafast") == 0 ? 2 : 3; /* (libx264: ultrafast analyses no i4x4 partitions) */
     param->hip.i_subpel = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 2;
     param->hip.i_deblock = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 1; /* (libx264: ultrafast sets no-deblock) */
     if (preset) {
@@ -207,7 +207,7 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     cfg.in_slots = h->pool;
     cfg.out_slots = h->pool;
     cfg.device = param->hip.i_device;
-    cfg.intra_modes = param->hip.i_intra_modes < 0 ? 0 : param->hip.i_intra_modes > 2 ? 2 : param->hip.i_intra_modes;
+    cfg.intra_modes = param->hip.i_intra_modes < 0 ? 0 : param->hip.i_intra_modes > 3 ? 3 : param->hip.i_intra_modes;
     cfg.deblock = param->hip.i_deblock != 0;
     /* sub-sample refinement: whole-picture encoders only (the six-tap filter reaches three rows past a band's halo) */
     cfg.subpel = (param->hip.i_slice_count <= 0 && param->hip.i_slice_first <= 0 && param->hip.i_rccl_world <= 0) ? param->hip.i_subpel : 0;
