@@ -55,7 +55,8 @@ struct dbk_strip {
                                        the strip, 1 .. DBK_S the strip --, [1] the row above (entries 1 .. DBK_S) */
 };
 
-#ifndef DBK_BRANCHFREE
+/* (A branch-free restatement with selects, the strong filter behind a wave-uniform test, was measured SLOWER: 376 -> 403 us per
+ * launch, 6.5 M -> 8.3 M vector instructions -- most lines fail the alpha / beta test and the branches skip the rest.) */
 /* one line across an edge: s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (chroma: p1 p0 q0 q1 in s[2..5]); 8.7.2.3 / 8.7.2.4 */
 DEVFN void dbk_line(int s[8], int bs, int alpha, int beta, int tc0, bool chroma) {
     const int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
@@ -85,39 +86,6 @@ DEVFN void dbk_line(int s[8], int bs, int alpha, int beta, int tc0, bool chroma)
             s[4] = (2 * q1 + q0 + p1 + 2) >> 2;
     }
 }
-#else
-/* one line across an edge: s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (chroma: p1 p0 q0 q1 in s[2..5]); 8.7.2.3 / 8.7.2.4.
- * Branch-free for the ordinary strengths (selects instead of nested branches: a row's macroblocks are one wave's serial
- * instruction stream, and a lone wave issues one vector instruction in ~8 cycles -- the filter's length in instructions IS
- * the launch time); the strong filter (bS = 4: intra macroblock edges) is computed only by waves one
- * of whose lines has it. */
-DEVFN void dbk_line(int s[8], int bs, int alpha, int beta, int tc0, bool chroma) {
-    const int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
-    const bool filt = bs != 0 && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta;
-    const bool ap = !chroma && abs(p2 - p0) < beta, aq = !chroma && abs(q2 - q0) < beta;
-    const int tc = chroma ? tc0 + 1 : tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
-    const int delta = min(max((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc), tc);
-    const int avg = (p0 + q0 + 1) >> 1;
-    int n2p = p2, n1p = ap ? p1 + min(max((p2 + avg - (p1 << 1)) >> 1, -tc0), tc0) : p1, n0p = venc_clip_u8(p0 + delta);
-    int n2q = q2, n1q = aq ? q1 + min(max((q2 + avg - (q1 << 1)) >> 1, -tc0), tc0) : q1, n0q = venc_clip_u8(q0 - delta);
-    if (__ballot(bs == 4) != 0ull) { /* (wave-uniform) */
-        const bool strong = bs == 4;
-        const bool small = !chroma && abs(p0 - q0) < ((alpha >> 2) + 2);
-        const bool sp = small && ap, sq = small && aq;
-        const int w0p = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-        const int w1p = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1;
-        const int w2p = sp ? (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2;
-        const int w0q = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-        const int w1q = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
-        const int w2q = sq ? (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
-        n0p = strong ? w0p : n0p, n1p = strong ? w1p : n1p, n2p = strong ? w2p : n2p;
-        n0q = strong ? w0q : n0q, n1q = strong ? w1q : n1q, n2q = strong ? w2q : n2q;
-    }
-    s[1] = filt ? n2p : p2, s[2] = filt ? n1p : p1, s[3] = filt ? n0p : p0;
-    s[4] = filt ? n0q : q0, s[5] = filt ? n1q : q1, s[6] = filt ? n2q : q2;
-}
-
-#endif
 
 __global__ __launch_bounds__(64 * DBK_MAX_WAVES) void k_deblock(venc_geom g, venc_bufs B, venc_step S, int planes) {
     extern __shared__ __attribute__((aligned(16))) dbk_strip s_t[]; /* one tile per wave of the block (the launcher sizes it) */

@@ -149,6 +149,10 @@ DEVFN void step_qparams(const venc_geom &g, const venc_bufs &B, const venc_step 
     }
 }
 
+/* Tried in round 3 and dropped: coding only the few blocks of a wave that hold a level, sixteen lanes per
+ * block with the inverse transform by wave shuffles (four blocks per pass, handed over through LDS).  ~170 fewer vector
+ * instructions per transforming wave, bit-exact -- and 2 % SLOWER on the whole pass (same-box A/B 144.3 -> 141.6 Gpx/s; k_me_fix
+ * 0.50 -> 0.59 ms per pass): the shuffles' latency lengthens the tail of every block, which is what bounds these kernels. */
 DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, const uint32_t cq[4],
                            const uint32_t pq[4], const venc_qparams &ql) {
     const int blk = lane & 15, gbase = lane & 48;
@@ -166,7 +170,8 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
     }
     venc_fdct4(res, w);
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
-    if (__ballot(valid && !blk_all_zero<false>(w, ql)) == 0ull) {
+    const unsigned long long nzb = __ballot(valid && !blk_all_zero<false>(w, ql));
+    if (nzb == 0ull) {
         /* every block of the wave quantises to zero: no levels, the reconstruction is the prediction */
         if (valid) {
             info->nnz[blk_y(blk) * 4 + blk_x(blk)] = 0;

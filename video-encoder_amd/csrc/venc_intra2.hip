@@ -480,7 +480,9 @@ DEVFN uint32_t i4_trial(i4_tile &T, const venc_qparams &q, int lane, bool aL, bo
 #pragma unroll
     for (int m = 0; m < 9; m++) tab[m] = i4_tab(m, x, y);
     const int cls = venc_pos_class(p);
-    const int mf = q.mf[cls], vv = q.v[cls] << q.per;
+    const int qm0 = __builtin_amdgcn_readfirstlane(q.mf[0]), qm1 = __builtin_amdgcn_readfirstlane(q.mf[1]), qm2 = __builtin_amdgcn_readfirstlane(q.mf[2]);
+    const int qv0 = __builtin_amdgcn_readfirstlane(q.v[0]), qv1 = __builtin_amdgcn_readfirstlane(q.v[1]), qv2 = __builtin_amdgcn_readfirstlane(q.v[2]);
+    const int mf = cls == 0 ? qm0 : cls == 1 ? qm1 : qm2, vv = (cls == 0 ? qv0 : cls == 1 ? qv1 : qv2) << q.per; /* (selects of opaque reads: no indexing into scratch) */
     int scan = 0; /* scan position of this lane's coefficient (raster p) */
 #pragma unroll
     for (int i = 0; i < 16; i++)
