@@ -96,7 +96,8 @@ typedef struct x264_param_t {
     } rc;
     struct {                /* engine extension, not part of libx264 */
         int i_device;       /* HIP device ordinal */
-        int i_gop_batch;    /* closed GOPs encoded in lock-step (1 = frame-by-frame streaming) */
+        int i_gop_batch;    /* closed GOPs encoded in lock-step (1 = frame-by-frame streaming); x264_param_default_preset: 10, or 1 with
+                               tune zerolatency */
         int i_gop_base;     /* index of this encoder's first GOP in the whole stream (GOP-sharded multi-GPU runs) */
         /* slice-parallel multi-GPU mode (BASELINE config 5): this encoder codes only
          * the slices [i_slice_first, i_slice_first + i_slice_count) of every picture (0, 0 = all) and calls

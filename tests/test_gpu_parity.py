@@ -432,7 +432,8 @@ def test_legacy_and_split_inter_kernels_agree(venc, legacy_lib):
         assert outs[0][t][5] == outs[1][t][5]
 
 
-def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
+@pytest.mark.parametrize("tune", ["zerolatency", "film"])  # film = the reference's default (av_encode.c:103): ten closed GOPs in lock-step, drained through the flush loop
+def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path, tune):
     """tools/encode_yuv: the reference's call sequence in C, YUV4MPEG2 in (include/venc_source.h), MP4 out
     (include/venc_mp4.h).  The samples in the file equal the oracle's slice NALs, the avcC parameter sets equal the
     oracle's, and the demultiplexed stream decodes to the oracle's reconstruction."""
@@ -446,7 +447,7 @@ def test_c_driver_y4m_in_mp4_out(venc, orc, tmp_path):
     y4m, mp4, es = str(tmp_path / "in.y4m"), str(tmp_path / "out.mp4"), str(tmp_path / "out.h264")
     _write_y4m(y4m, frames, w, h, header_extra="F24:1 Ip A1:1 C420mpeg2")
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "encode_yuv")
-    out = subprocess.check_output([tool, "-i", y4m, "-n", "100", "-q", "27", "-S", str(slices), "-k", str(keyint), "-t", "zerolatency",
+    out = subprocess.check_output([tool, "-i", y4m, "-n", "100", "-q", "27", "-S", str(slices), "-k", str(keyint), "-t", tune,
                                    "-o", es, "-m", mp4])
     rep = json.loads(out.decode().strip().splitlines()[-1])
     assert rep["frames"] == n and rep["violations"] == 0 and rep["sync_samples"] == 3

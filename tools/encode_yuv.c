@@ -84,7 +84,7 @@ static bool enc_x264_open(int width, int height, int fps_num, int fps_den, int s
     params.rc.f_rf_constant = (float)quality;
     params.i_slice_count = slices;
     params.i_keyint_max = keyint;
-    params.hip.i_gop_batch = gop_batch;
+    if (gop_batch > 0) params.hip.i_gop_batch = gop_batch; /* (0: what the preset / tune chose: 10 GOPs in lock-step, 1 under zerolatency) */
     /* the preset's coding tools can be pinned for measurements: VENC_SUBPEL=0/1/2 (sub-sample refinement; preset default 2,
      * ultrafast 0), VENC_INTRA_MODES=0/1/2/3 (Intra16x16 DC only / V, H, DC / plane as well / Intra4x4 tried against that; preset default 3, ultrafast 2),
      * VENC_DEBLOCK=0/1 (in-loop filter; preset default 1, ultrafast 0) */
@@ -224,7 +224,7 @@ static double now_s(void) {
 }
 
 int main(int argc, char **argv) {
-    int w = 0, h = 0, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 1, fps = 30, fps_den = 1, sar_num = 1, sar_den = 1;
+    int w = 0, h = 0, frames = 30, qp = 26, slices = 8, keyint = 30, gop_batch = 0, fps = 30, fps_den = 1, sar_num = 1, sar_den = 1;
     int fps_given = 0;
     const char *in = NULL, *out = NULL, *mp4 = NULL, *tune = "film", *preset = "medium", *profile = NULL;
     /* the reference's default (av_encode.c:92); VENC_ASSUME_TTY=1 stands in for a terminal where none can be had (test boxes without pty devices) */

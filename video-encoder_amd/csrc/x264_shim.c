@@ -121,7 +121,9 @@ int x264_param_default_preset(x264_param_t *param, const char *preset, const cha
     param->rc.i_qp_constant = 26;
     param->rc.f_rf_constant = 23.0f;
     param->hip.i_device = 0;
-    param->hip.i_gop_batch = 1;
+    param->hip.i_gop_batch = 10; /* closed GOPs coded in lock-step (tune zerolatency: 1, below).  A caller shaped like the reference -- a file
+                                    transcoder that drains the encoder through x264_encoder_delayed_frames (av_encode.c:1076) -- wants the
+                                    chip filled, not the first frame early; libx264's own presets delay output by their lookahead too */
     param->hip.i_intra_modes = preset && strcmp(preset, "ultrafast") == 0 ? 2 : 3; /* (libx264: ultrafast analyses no i4x4 partitions) */
     param->hip.i_subpel = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 2;
     param->hip.i_deblock = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 1; /* (libx264: ultrafast sets no-deblock) */
@@ -135,7 +137,7 @@ int x264_param_default_preset(x264_param_t *param, const char *preset, const cha
         snprintf(buf, sizeof(buf), "%s", tune);
         for (char *tok = strtok(buf, ",./-+ "); tok; tok = strtok(NULL, ",./-+ ")) {
             if (!name_in(tok, k_tunes)) return -1;
-            if (!strcmp(tok, "zerolatency")) param->b_zerolatency = 1;
+            if (!strcmp(tok, "zerolatency")) param->b_zerolatency = 1, param->hip.i_gop_batch = 1;
         }
         snprintf(param->psz_tune, sizeof(param->psz_tune), "%.15s", tune);
     }
