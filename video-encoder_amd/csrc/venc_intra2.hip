@@ -463,13 +463,24 @@ DEVFN int i4_fwd1d(int t, int a, int b, int c, int d) { /* Cf = [1 1 1 1; 2 1 -1
     return t == 0 ? a + b + c + d : t == 1 ? 2 * a + b - c - 2 * d : t == 2 ? a - b - c + d : a - 2 * b + 2 * c - d;
 }
 
-/* The trial.  Called by all lanes of the macroblock's half-wave (l32 = lane & 31; lanes 16 .. 31 only ride along); the
- * tile's row -1 / column -1 / corner and its source samples are in place.  aL, aT, aTR: the macroblock to the left, above,
- * above-right is in the slice (the one above-left is iff both aL and aT).  Returns the sum of the sixteen blocks' SADs
- * (the same in every lane of the half); reconstruction, levels, counts and modes are left in the tile. */
-DEVFN uint32_t i4_trial(i4_tile &T, const venc_qparams &q, int lane, bool aL, bool aT, bool aTR) {
-    const int l32 = lane & 31, hbase = lane & 32, p = l32 & 15, x = p & 3, y = p >> 2;
-    const bool px = l32 < 16;
+/* sum over the 16 lanes of a DPP row, the same in each of them */
+DEVFN uint32_t i4_row_sum(uint32_t v, int lane) {
+    v += dpp_fetch<DPP_ROW_SHR(1), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(2), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(4), 0xf>(v, 0u);
+    v += dpp_fetch<DPP_ROW_SHR(8), 0xf>(v, 0u);
+    return (uint32_t)__shfl((int)v, (lane & 48) | 15);
+}
+
+/* The trial.  Called by all 32 lanes of the macroblock's half-wave; the tile's row -1 / column -1 / corner and its source
+ * samples are in place.  A block waits only for its left, upper, upper-left and upper-right neighbours, so the sixteen blocks
+ * go in TEN rounds -- round L = the blocks with bx + 2 by = L, at most two of them, one on lanes 0-15 of the half and one on
+ * lanes 16-31 (the chroma lanes, idle here).  aL, aT, aTR: the macroblock to the left, above, above-right is in the slice
+ * (the one above-left iff both aL and aT).  best16 = the SAD the trial has to beat: once the sum of the blocks done reaches
+ * it in both halves of the wave, the rest is skipped.  Returns the sum of the sixteen blocks' SADs (or a partial sum
+ * >= best16), the same in every lane of the half; reconstruction, levels, counts and modes are left in the tile. */
+DEVFN uint32_t i4_trial(i4_tile &T, const venc_qparams &q, int lane, bool aL, bool aT, bool aTR, uint32_t best16) {
+    const int grp = lane & 48, second = (lane >> 4) & 1, p = lane & 15, x = p & 3, y = p >> 2;
     uint8_t *const rec = (uint8_t *)T.rec;
     const uint8_t *const src = (const uint8_t *)T.src;
     /* where this lane's entry of E' sits relative to the block's top-left sample: lanes 0, 1 L3; 2 L2; 3 L1; 4 L0; 5 the corner;
@@ -487,40 +498,45 @@ DEVFN uint32_t i4_trial(i4_tile &T, const venc_qparams &q, int lane, bool aL, bo
 #pragma unroll
     for (int i = 0; i < 16; i++)
         if (venc_zigzag_ct(i) == p) scan = i;
-    uint32_t total = 0;
-    for (int k = 0; k < 16; k++) {
-        const int bx = blk_x(k), by = blk_y(k);
-        const bool top = by > 0 || aT, left = bx > 0 || aL;
-        const bool corner = (bx > 0 && by > 0) || (bx == 0 && by > 0 && aL) || (bx > 0 && by == 0 && aT) || (bx == 0 && by == 0 && aL && aT);
-        const bool topright = by == 0 ? (bx < 3 ? aT : aTR) : (bx < 3 && blk_of(bx + 1, by - 1) < k);
-        uint8_t *const o = rec + (4 * by + 1) * I4_RS + 4 + 4 * bx; /* the block's top-left sample in the tile */
+    uint32_t total = 0; /* SADs of the blocks this lane's group has done */
+    for (int L = 0; L < 10; L++) {
+        /* the block of this lane's group in round L: (bx, by) with bx + 2 by = L; the first group takes the upper one */
+        const int by0 = L <= 3 ? 0 : (L - 2) >> 1; /* smallest by with bx = L - 2 by <= 3 */
+        const int by = by0 + second, bx = L - 2 * by;
+        const bool act = bx >= 0 && by <= 3;
+        const int k = act ? blk_of(bx, by) : 0;
+        const int cbx = act ? bx : 0, cby = act ? by : 0;
+        const bool top = cby > 0 || aT, left = cbx > 0 || aL;
+        const bool corner = (cbx > 0 && cby > 0) || (cbx == 0 && cby > 0 && aL) || (cbx > 0 && cby == 0 && aT) || (cbx == 0 && cby == 0 && aL && aT);
+        const bool topright = cby == 0 ? (cbx < 3 ? aT : aTR) : (cbx < 3 && blk_of(cbx + 1, cby - 1) < k);
+        uint8_t *const o = rec + (4 * cby + 1) * I4_RS + 4 + 4 * cbx; /* the block's top-left sample in the tile */
         /* ---- the edge vector and the three numbers per lane ---- */
         const int ec = (!topright && e_col > 3) ? 3 : e_col;
         const uint32_t e = o[e_row * I4_RS + ec];
-        const uint32_t ep = (uint32_t)__shfl((int)e, hbase | ((p + 15) & 15)), en = (uint32_t)__shfl((int)e, hbase | ((p + 1) & 15));
+        const uint32_t ep = (uint32_t)__shfl((int)e, grp | ((p + 15) & 15)), en = (uint32_t)__shfl((int)e, grp | ((p + 1) & 15));
         const uint32_t pk = e | (((ep + 2u * e + en + 2u) >> 2) << 8) | (((e + en + 1u) >> 1) << 16);
         /* ---- the nine predictors of this lane's sample ---- */
         int pm[9];
 #pragma unroll
         for (int m = 0; m < 9; m++) {
             if (m == 2) continue;
-            const uint32_t v = (uint32_t)__shfl((int)pk, hbase | (tab[m] & 15));
+            const uint32_t v = (uint32_t)__shfl((int)pk, grp | (tab[m] & 15));
             pm[m] = (int)((v >> (8 * (tab[m] >> 4))) & 255u);
         }
         {
             const uint32_t part = ((p >= 6 && p <= 9) ? e : 0u) | ((p >= 1 && p <= 4) ? e << 16 : 0u);
-            const uint32_t sums = half_sum32(px ? part : 0u, lane);
+            const uint32_t sums = i4_row_sum(part, lane);
             const int sT = (int)(sums & 0xffffu), sL = (int)(sums >> 16);
             pm[2] = (top && left) ? (sT + sL + 4) >> 3 : left ? (sL + 2) >> 2 : top ? (sT + 2) >> 2 : 128;
         }
         /* ---- SADs, the choice ---- */
-        const int sv = (int)src[(4 * by + y) * 16 + 4 * bx + x];
+        const int sv = (int)src[(4 * cby + y) * 16 + 4 * cbx + x];
         uint32_t d[9];
 #pragma unroll
-        for (int m = 0; m < 9; m++) d[m] = px ? (uint32_t)abs(sv - pm[m]) : 0u;
-        const uint32_t s01 = half_sum32(d[0] | (d[1] << 16), lane), s23 = half_sum32(d[2] | (d[3] << 16), lane);
-        const uint32_t s45 = half_sum32(d[4] | (d[5] << 16), lane), s67 = half_sum32(d[6] | (d[7] << 16), lane);
-        const uint32_t s8 = half_sum32(d[8], lane);
+        for (int m = 0; m < 9; m++) d[m] = (uint32_t)abs(sv - pm[m]);
+        const uint32_t s01 = i4_row_sum(d[0] | (d[1] << 16), lane), s23 = i4_row_sum(d[2] | (d[3] << 16), lane);
+        const uint32_t s45 = i4_row_sum(d[4] | (d[5] << 16), lane), s67 = i4_row_sum(d[6] | (d[7] << 16), lane);
+        const uint32_t s8 = i4_row_sum(d[8], lane);
         const bool tlc = top && left && corner;
         const uint32_t sad[9] = {top ? s01 & 0xffffu : 0xffffu, left ? s01 >> 16 : 0xffffu, s23 & 0xffffu, top ? s23 >> 16 : 0xffffu,
                                  tlc ? s45 & 0xffffu : 0xffffu, tlc ? s45 >> 16 : 0xffffu, tlc ? s67 & 0xffffu : 0xffffu,
@@ -530,32 +546,33 @@ DEVFN uint32_t i4_trial(i4_tile &T, const venc_qparams &q, int lane, bool aL, bo
 #pragma unroll
         for (int m = 1; m < 9; m++)
             if (sad[m] < best) best = sad[m], bm = m, pred = pm[m];
-        total += best;
+        if (act) total += best;
         /* ---- residual -> coefficient of this lane (row pass, then column pass) ---- */
         const int r0 = sv - pred;
-        const int ra = __shfl(r0, hbase | (4 * y)), rb = __shfl(r0, hbase | (4 * y + 1)), rc = __shfl(r0, hbase | (4 * y + 2)), rd = __shfl(r0, hbase | (4 * y + 3));
+        const int ra = __shfl(r0, grp | (4 * y)), rb = __shfl(r0, grp | (4 * y + 1)), rc = __shfl(r0, grp | (4 * y + 2)), rd = __shfl(r0, grp | (4 * y + 3));
         const int h1 = i4_fwd1d(x, ra, rb, rc, rd);
-        const int ca = __shfl(h1, hbase | x), cb = __shfl(h1, hbase | (4 + x)), cc = __shfl(h1, hbase | (8 + x)), cd = __shfl(h1, hbase | (12 + x));
+        const int ca = __shfl(h1, grp | x), cb = __shfl(h1, grp | (4 + x)), cc = __shfl(h1, grp | (8 + x)), cd = __shfl(h1, grp | (12 + x));
         const int w = i4_fwd1d(y, ca, cb, cc, cd);
         const int lvl = venc_quant_mag(w, mf, q.f_intra, q.qbits);
-        const uint32_t nzb = (uint32_t)(__ballot(px && lvl != 0) >> hbase) & 0xffffu;
-        if (px) ((int16_t *)T.lv)[k * 16 + scan] = (int16_t)lvl;
+        const uint32_t nzb = (uint32_t)(__ballot(act && lvl != 0) >> grp) & 0xffffu;
+        if (act) ((int16_t *)T.lv)[k * 16 + scan] = (int16_t)lvl;
         /* ---- back: dequantisation, inverse transform (rows first, 8.5.12.2), reconstruction ---- */
         const int dq = VENC_MUL24(lvl, vv);
-        const int ia = __shfl(dq, hbase | (4 * y)), ib = __shfl(dq, hbase | (4 * y + 1)), ic = __shfl(dq, hbase | (4 * y + 2)), id = __shfl(dq, hbase | (4 * y + 3));
+        const int ia = __shfl(dq, grp | (4 * y)), ib = __shfl(dq, grp | (4 * y + 1)), ic = __shfl(dq, grp | (4 * y + 2)), id = __shfl(dq, grp | (4 * y + 3));
         const int f1 = i4_inv1d(x, ia, ib, ic, id);
-        const int ja = __shfl(f1, hbase | x), jb = __shfl(f1, hbase | (4 + x)), jc = __shfl(f1, hbase | (8 + x)), jd = __shfl(f1, hbase | (12 + x));
+        const int ja = __shfl(f1, grp | x), jb = __shfl(f1, grp | (4 + x)), jc = __shfl(f1, grp | (8 + x)), jd = __shfl(f1, grp | (12 + x));
         const int rr = (i4_inv1d(y, ja, jb, jc, jd) + 32) >> 6;
-        if (px) {
+        if (act) {
             o[y * I4_RS + x] = (uint8_t)venc_clip_u8(pred + rr);
             if (p == 0) {
                 ((uint8_t *)T.nz)[k] = (uint8_t)__popc(nzb);
                 ((uint8_t *)T.mode)[k] = (uint8_t)bm;
             }
         }
-        /* (the next block reads the tile: LDS operations of a wave are ordered) */
+        /* (the next round reads the tile: LDS operations of a wave are ordered) */
+        if (__ballot(total + (uint32_t)__shfl((int)total, lane ^ 16) < best16) == 0ull) break; /* neither macroblock of the wave can still win */
     }
-    return total;
+    return total + (uint32_t)__shfl((int)total, lane ^ 16);
 }
 
 /* ================================================================== k_intra_modes
@@ -705,7 +722,7 @@ __global__ __launch_bounds__(I4 ? 64 * INTRA4_MAX_WAVES : 1024) void k_intra_mod
 #pragma unroll
                         for (int y = 0; y < 4; y++) T4.src[(by + y) * 4 + (bx >> 2)] = cq[y];
                     }
-                    const uint32_t tot4 = i4_trial(T4, g.ql, lane, aL, aT, aTR);
+                    const uint32_t tot4 = i4_trial(T4, g.ql, lane, aL, aT, aTR, best);
                     use_i4 = tot4 < best;
                 }
                 const int px = (luma ? mx * 16 : mx * 8) + bx, py = (luma ? my * 16 : my * 8) + by;
