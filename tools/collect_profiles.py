@@ -14,7 +14,8 @@ dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 names = {"bench_default": "bench_default_1080p_with_2160p_pcie_cpu_bitexact", "bench_1080p": "bench_1080p", "bench_2160p": "bench_2160p",
          "bench_1080p_serial": "bench_1080p_serial_steps",
          "bench_2160p_serial": "bench_2160p_serial_steps", "bench_slices1": "bench_2160p_slices_1rank",
-         "bench_slices2": "bench_2160p_slices_2rank_gloo_rehearsal", "bench_streams2": "bench_1080p_streams_2rank_gloo_rehearsal"}
+         "bench_slices2": "bench_2160p_slices_2rank_gloo_rehearsal", "bench_streams2": "bench_1080p_2rank_gloo_rehearsal_self_launched_with_slices_leg",
+         "bench_streams2_torchrun": "bench_1080p_2rank_gloo_rehearsal_torchrun_with_slices_leg"}
 for p in glob.glob(os.path.join(src, "bench_tool_*.json")):
     names[os.path.basename(p)[:-5]] = os.path.basename(p)[:-5]
 ks = glob.glob(os.path.join(src, "stats_tools", "*", "*kernel_stats.csv"))
@@ -48,4 +49,9 @@ for wl in ("1080p", "2160p"):
     p = os.path.join(src, "sq_counters_%s_isolated.txt" % wl)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, "%s_sq_counters_%s_isolated.txt" % (tag, wl)))
+for a, b in (("me_phase_1080p.txt", "me_phase_1080p.txt"), ("valu_ubench.txt", "valu_ubench.txt"), ("h2d_ubench.txt", "h2d_ubench.txt"),
+             ("deblock_waves_per_block.txt", "deblock_waves_per_block.txt"), ("deblock_sq_counters.txt", "deblock_sq_counters.txt")):
+    p = os.path.join(src, a)
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, b)))
 print("\n".join(sorted(f for f in os.listdir(dst) if f.startswith(tag))))

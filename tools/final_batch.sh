@@ -19,13 +19,13 @@ timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 timeout -k 10 300 python bench.py --workload 2160p $Q > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
 timeout -k 10 300 python bench.py --serial-steps $Q > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
 # the optional coding tools (each checked bit-exact against the oracle on the first GOP), 1080p and for sub-sample refinement 2160p
-for v in "crf:--crf 26" "intra_modes:--intra-modes" "subpel1:--subpel 1" "subpel2:--subpel 2" "deblock:--deblock" "intra_modes_plane:--intra-modes 2" "all_tools:--crf 26 --intra-modes 2 --subpel 2 --deblock" "preset_tools_no_filter:--crf 26 --intra-modes 2 --subpel 2"; do
+for v in "crf:--crf 26" "intra_modes:--intra-modes" "subpel1:--subpel 1" "subpel2:--subpel 2" "deblock:--deblock" "deblock_gop_batch10:--deblock --gop-batch 10" "intra_modes_plane:--intra-modes 2" "intra4x4:--intra-modes 3" "all_tools:--crf 26 --intra-modes 3 --subpel 2 --deblock" "all_tools_gop_batch10:--crf 26 --intra-modes 3 --subpel 2 --deblock --gop-batch 10" "all_tools_r02_set_gop_batch10:--crf 26 --intra-modes 2 --subpel 2 --deblock --gop-batch 10" "preset_tools_no_filter:--crf 26 --intra-modes 3 --subpel 2"; do
   timeout -k 10 300 python bench.py --no-extras --cpu-frames 30 ${v#*:} > $O/bench_tool_${v%%:*}.json 2> $O/bench_tool_${v%%:*}.err; cut -c1-160 $O/bench_tool_${v%%:*}.json
 done
 timeout -k 10 300 python bench.py --workload 2160p --no-extras --cpu-frames 0 --subpel 2 > $O/bench_tool_subpel2_2160p.json 2> $O/bench_tool_subpel2_2160p.err
 # sub-sample mode and the in-loop filter: kernel stats, every kernel alone on the chip
 cd /tmp
-VENC_NO_OVERLAP=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_tools -- python3 $R/bench.py --steps 2 --warmup 1 $Q --no-profile --subpel 2 --deblock --crf 26 --intra-modes 2 > $O/stats_tools.log 2>&1
+VENC_NO_OVERLAP=1 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_tools -- python3 $R/bench.py --steps 2 --warmup 1 $Q --no-profile --subpel 2 --deblock --crf 26 --intra-modes 3 --gop-batch 10 > $O/stats_tools.log 2>&1
 cd $R
 cd /tmp
 for wl in 1080p 2160p; do
@@ -40,12 +40,21 @@ for wl in 1080p 2160p; do
   echo "sq $wl done"
 done
 cd $R
-for wl in 1080p 2160p; do python3 tools/sq_summary.py $O/sq_$wl $wl > $O/sq_counters_${wl}_isolated.txt 2> $O/sq_summary_$wl.err; done
+for wl in 1080p 2160p; do python3 tools/sq_summary.py $O/sq_$wl $wl profiles/sq_counters.json > $O/sq_counters_${wl}_isolated.txt 2> $O/sq_summary_$wl.err; done
+cp profiles/sq_counters.json $O/
 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --mode slices --workload 2160p $Q > $O/bench_slices1.json 2> $O/bench_slices1.err; cut -c1-240 $O/bench_slices1.json
-timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --steps 3 --warmup 1 --gpus 2 --mode slices --workload 2160p --backend gloo --device 0 $Q > $O/bench_slices2.json 2> $O/bench_slices2.err
-grep -o '"bitstream_sha256": "[0-9a-f]*"' $O/bench_slices2.json
-timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --steps 3 --warmup 1 --gpus 2 --backend gloo --device 0 $Q > $O/bench_streams2.json 2> $O/bench_streams2.err
+# two ranks on the one GPU (gloo rehearsal of the N > 1 run: bench.py starts its own ranks; the line carries the config-5 leg as slices_2160p)
+timeout -k 10 500 python bench.py --gpus 2 --device 0 --backend gloo --steps 3 --warmup 1 $Q --slices-steps 2 > $O/bench_streams2.json 2> $O/bench_streams2.err
 cut -c1-200 $O/bench_streams2.json
+# the same under the driver's launcher
+timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --steps 3 --warmup 1 --gpus 2 --backend gloo --device 0 $Q --slices-steps 2 > $O/bench_streams2_torchrun.json 2> $O/bench_streams2_torchrun.err
+grep -o '"equals_one_rank_bitstream": [a-z]*' $O/bench_streams2.json $O/bench_streams2_torchrun.json
+# round 3: the search kernel's phase budget, instruction issue costs, ingest copy ceiling, the in-loop filter against waves per block
+bash tools/me_phase_pmc.sh ${1:-final}/phase 1080p > /dev/null 2>&1; cp $O/phase/me_phase_1080p.txt $O/ 2>/dev/null
+tools/valu_ubench > $O/valu_ubench.txt 2>&1
+tools/h2d_ubench > $O/h2d_ubench.txt 2>&1
+bash tools/r03_dbk_waves.sh ${1:-final}/dbkw > $O/deblock_waves_per_block.txt 2>&1
+bash tools/r03_dbk_pmc.sh ${1:-final}/dbkpmc libvenc_hip.so > $O/deblock_sq_counters.txt 2>&1
 # keep the merged output small: the raw traces stay on the box
 for d in $O/pmcf_* $O/pmcw_* $O/stats_* $O/sq_1080p $O/sq_2160p; do [ -d "$d" ] && find $d -name "*agent_info.csv" -delete; done
 du -sh $O
