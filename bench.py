@@ -482,7 +482,10 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             res["config"]["exchange"] = "C, RCCL (venc_band_exchange_rccl)" if c_exchange else "Python, torch.distributed %s (rehearsal)" % args.backend
             n_x = venc.hip_lib().venc_rccl_exchanges(eng) if c_exchange else xc.exchanges
             res["config"]["exchanges_per_step"] = int(n_x) // max(1, steps + warmup)
-            res["config"]["exchanges_per_picture"] = round(res["config"]["exchanges_per_step"] / float(frames), 4)
+            # one exchange call serves every item (closed GOP) of a lock-step step: per picture = calls x items per call / pictures
+            n_gops = (frames + keyint - 1) // keyint
+            res["config"]["exchange_calls_per_step"] = res["config"]["exchanges_per_step"]
+            res["config"]["exchanges_per_picture"] = round(res["config"]["exchanges_per_step"] * min(gop_batch, n_gops) / float(frames), 4)
             if c_exchange:
                 res["config"]["rccl_ranks"] = int(venc.hip_lib().venc_rccl_comm_count(eng))  # ncclCommCount of the engine's communicator
             if world > 1:

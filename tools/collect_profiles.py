@@ -54,4 +54,18 @@ for a, b in (("me_phase_1080p.txt", "me_phase_1080p.txt"), ("valu_ubench.txt", "
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, b)))
+# the kept counter files: taken from the batch, stamped with the commit they were collected at (the GPU box's copy has no .git)
+import json
+import subprocess
+try:
+    head = subprocess.check_output(["git", "-C", dst, "rev-parse", "--short", "HEAD"]).decode().strip()
+except Exception:
+    head = None
+for name in ("pmc_traffic.json", "sq_counters.json"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        doc = json.load(open(p))
+        if isinstance(doc.get("source"), dict) and not doc["source"].get("git_head"):
+            doc["source"]["git_head"] = head
+        json.dump(doc, open(os.path.join(dst, name), "w"), indent=1)
 print("\n".join(sorted(f for f in os.listdir(dst) if f.startswith(tag))))
