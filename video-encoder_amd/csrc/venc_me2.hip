@@ -55,7 +55,10 @@ DEVFN uint2 pk4_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y);
  * clip) run side by side instead of dragging whole tiles along.  The four waves of a block split
  * the 33 vertical displacements (9 each, the last wave's tail is masked); lane = horizontal
  * displacement.  k_me_tile appended the macroblock indices to fix_list / fix_count. */
-#define FIX_BLOCKS 256 /* per item: one listed macroblock per block in all but pathological pictures (a block that loops costs the step a second search latency) */
+#ifndef FIX_BLOCKS
+#define FIX_BLOCKS 256
+#endif
+/* (FIX_BLOCKS:  per item: one listed macroblock per block in all but pathological pictures (a block that loops costs the step a second search latency) */
 #define FIX_WD 13 /* window row: 48 bytes + 4 spare, in dwords */
 #define FIX_NDY 9   /* vertical displacements per wave: 4 waves cover 36 >= 33.  (8 waves x 5: k_me_fix 17 -> 26 us per launch, 1080p 149 -> 143
                        Gpx/s; 16 x 3 spills at the 128-register cap of a 1024-thread block.  Every wave pays the 64 LDS reads of the
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
             const int dx = dxi - 16, dy = dy0 + mine_k - 16;
             if (RC) { /* the picture's SAD sum holds what k_me_pool found for this macroblock: correct it */
                 const uint32_t old = B.mvsad[(size_t)item * g.nmb + mb] >> 16;
-                atomicAdd(&B.sad_cur[item], (unsigned long long)(long long)((int)(best >> 11) - (int)old));
+                const unsigned long long before = atomicAdd(&B.sad_cur[item], (unsigned long long)(long long)((int)(best >> 11) - (int)old));
+                asm volatile("" ::"v"((uint32_t)before)); /* (consumed: the wave waits for the atomic's return) */
             }
             B.mvsad[(size_t)item * g.nmb + mb] = ((best >> 11) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
             s_mv[0] = dxi, s_mv[1] = dy0 + mine_k; /* window position of the winner */
@@ -196,10 +200,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
      * reports in last derives the NEXT picture's QP from it (spec/CODEC.md section 1a: the one 64-bit division per picture
      * and item) and leaves it in the next step's slot of the QP ring, where that step's kernels find it. */
     if (RC) {
-        /* every thread's correction must have reached L2, where the sum lives, before this block reports in: the atomics
-         * above are fire-and-forget and a workgroup barrier alone does not wait for them (no vmcnt(0) at workgroup scope
-         * outside tgsplit mode); the agent-scope release does, and correction and arrival go to different L2 channels */
-        __threadfence();
+        /* every correction above was a RETURNING atomic whose result the thread consumed: it has been performed (device-wide, at
+         * the memory side) before the thread got here, so the arrival below cannot overtake it.  (An agent-scope fence does the
+         * same and costs 0.9 ms per 1080p pass: it writes back and invalidates the L2 the search has just filled -- k_me_fix
+         * 0.54 -> 1.46 ms, `--crf` 129 -> 115 Gpx/s, same-box A/B gpurun_out/r03_fixx.) */
         __syncthreads();
         if (tid == 0) {
             if (atomicAdd(&B.fix_done[item], 1u) == reporting - 1u) {
