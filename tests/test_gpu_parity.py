@@ -158,6 +158,46 @@ def test_rotating_input_pictures_equal_the_single_picture_stream(venc, gop_batch
     assert [f.payload for f in got] == [f.payload for f in a]
 
 
+@pytest.mark.parametrize("gop_batch,depth", [(1, 1), (3, 1), (3, 2)])
+def test_host_frames_loop_in_c_equals_the_per_call_stream(venc, gop_batch, depth):
+    """x264_venc_encode_host_frames -- the reference's loop (av_encode.c:543-547, :970, :1076-1083) in C over frames in pinned host
+    memory, what bench.py's ingest-inclusive leg times -- delivers the frames the per-call Python loop delivers, in order, with the
+    tally's per-pass delivery stamps set."""
+    import ctypes as C
+    w, h, n = 176, 144, 17
+    frames = [venc.synth_frame(w, h, t, 11) for t in range(n)]
+    a = _x264_stream(venc, frames, w, h, qp=29, slices=3, keyint=4, gop_batch=gop_batch)
+    H, L = venc.hip_lib(), venc.x264_lib()
+    fb = w * h * 3 // 2
+    hp = H.venc_host_alloc(n * fb)
+    assert hp
+    try:
+        host = np.ctypeslib.as_array((C.c_uint8 * (n * fb)).from_address(hp))
+        for t, (y, u, v) in enumerate(frames):
+            host[t * fb:(t + 1) * fb] = np.concatenate([y.ravel(), u.ravel(), v.ravel()])
+        enc = venc.X264Encoder(w, h, qp=29, slices=3, keyint=4, gop_batch=gop_batch, input_depth=depth)
+        got = []
+
+        def sink(user, nals, n_nals, size, pic):
+            got.append(C.string_at(nals[0].p_payload, size))
+            return 0
+        cb = venc.SINK_FN(sink)
+        L.x264_venc_encode_host_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        assert L.x264_venc_encode_host_frames(enc.h, C.c_void_p(hp), fb, w, h, n, 1, C.cast(cb, C.c_void_p), None) == n
+        assert got == [f.payload for f in a]
+        enc.close()
+        # two passes over the first 16 frames (whole GOPs) as one stream, counted by the C tally sink with its per-pass stamps
+        enc = venc.X264Encoder(w, h, qp=29, slices=3, keyint=4, gop_batch=gop_batch, input_depth=depth)
+        t = venc.X264Tally()
+        t.pass_frames = 16
+        assert L.x264_venc_encode_host_frames(enc.h, C.c_void_p(hp), fb, w, h, 16, 2, C.cast(L.x264_venc_tally_sink, C.c_void_p), C.cast(C.pointer(t), C.c_void_p)) == 32
+        assert t.frames == 32 and t.passes == 2 and 0 < t.pass_end_ns[0] <= t.pass_end_ns[1]
+        assert t.bytes == 2 * sum(len(f.payload) for f in a[:16])
+        enc.close()
+    finally:
+        H.venc_host_free(hp)
+
+
 def test_gop_batched_equals_streaming(venc):
     w, h, n = 352, 288, 40
     frames = [venc.synth_frame(w, h, t, 99) for t in range(n)]
