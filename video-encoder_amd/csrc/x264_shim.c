@@ -64,6 +64,8 @@ struct x264_t {
     int nal_cap;
     int external_input; /* venc_set_input is active (resident mode) */
     double trace_t0;    /* VENC_TRACE: start of the resident call (0 = no trace) */
+    double enc_ms[5];   /* VENC_TRACE: x264_encoder_encode's host time by part: upload, wait for the copy, launches, delivery; [4] = calls */
+    int enc_trace;
     int64_t ext_clip;   /* resident mode: frames in the resident clip; stream frame f reads clip frame f % ext_clip */
     int band_first, band_count; /* slices coded by this encoder (slice-parallel mode), 0/0 = all */
     int rccl;                   /* the engine exchanges bands itself over RCCL (hip.i_rccl_world > 0) */
@@ -189,6 +191,7 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     h->gop_counter = param->hip.i_gop_base > 0 ? param->hip.i_gop_base : 0;
     h->gop_batch = param->hip.i_gop_batch > 1 ? param->hip.i_gop_batch : 1;
     h->input_depth = param->hip.i_input_depth > 1 ? param->hip.i_input_depth : 1;
+    h->enc_trace = getenv("VENC_TRACE") != NULL;
     if (h->gop_batch > VENC_MAX_ITEMS) h->gop_batch = VENC_MAX_ITEMS;
     if (h->gop_batch > 1) {
         h->unit = h->gop_batch * h->keyint;
@@ -287,6 +290,9 @@ x264_t *x264_encoder_open(x264_param_t *param) {
 
 void x264_encoder_close(x264_t *h) {
     if (!h) return;
+    if (h->enc_trace && h->enc_ms[4] > 0)
+        fprintf(stderr, "venc trace: x264_encoder_encode, %.0f calls with a picture: per call upload %.1f us, wait for the copy %.1f us, launches %.1f us, delivery %.1f us\n",
+                h->enc_ms[4], 1e3 * h->enc_ms[0] / h->enc_ms[4], 1e3 * h->enc_ms[1] / h->enc_ms[4], 1e3 * h->enc_ms[2] / h->enc_ms[4], 1e3 * h->enc_ms[3] / h->enc_ms[4]);
     if (h->worker_on) {
         pthread_mutex_lock(&h->mtx);
         h->w_stop = 1;
@@ -521,9 +527,11 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         fr->out_slot = (int)(f % h->pool);
         fr->ticket = -1;
         fr->assembled = 0;
+        const double tt0 = h->enc_trace ? now_ms() : 0;
         if (venc_upload(h->ctx, (int)(f % h->pool), pic_in->img.plane[0], pic_in->img.i_stride[0], pic_in->img.plane[1],
                         pic_in->img.i_stride[1], pic_in->img.plane[2], pic_in->img.i_stride[2]) != 0)
             return -1;
+        const double tt1 = h->enc_trace ? now_ms() : 0;
         /* the caller rewrites pic_in right after this call (av_encode.c:545): wait for the ingest copy -- on its own stream,
          * so this does not wait for the kernels of earlier frames, which keep running beside the copy of the next frame */
         if (h->input_depth > 1) { /* hip.i_input_depth: the picture handed over input_depth - 1 calls ago is the next one the caller fills */
@@ -531,8 +539,19 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         } else if (venc_upload_sync(h->ctx) != 0)
             return -1;
         h->n_in++;
+        const double tt2 = h->enc_trace ? now_ms() : 0;
         if (launch_pending(h, 0) != 0) return -1;
+        if (h->enc_trace) {
+            const double tt3 = now_ms();
+            h->enc_ms[0] += tt1 - tt0, h->enc_ms[1] += tt2 - tt1, h->enc_ms[2] += tt3 - tt2, h->enc_ms[4] += 1;
+        }
         if (h->n_in - h->n_out <= h->delay) return 0;
+        if (h->enc_trace) {
+            const double tt4 = now_ms();
+            const int r = deliver(h, pp_nal, pi_nal, pic_out);
+            h->enc_ms[3] += now_ms() - tt4;
+            return r;
+        }
     } else {
         if (h->n_in == h->n_out) return 0;
         if (launch_pending(h, 1) != 0) return -1;
