@@ -306,6 +306,7 @@ def test_intra_three_kernels_equal_the_wavefront_kernel(venc, legacy_lib, w, h, 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [
     {"VENC_FUSE": "0"},                 # luma + chroma transform as k_inter_fused on the main chain (round 1's shape)
+    {"VENC_FUSE": "1"},                 # every luma block coded inside the search kernels (round 2's shape; default: blocks with a level behind them)
     {"VENC_FUSE": "2"},                 # chroma transform inside the search kernels too
     {"VENC_ENTROPY_BATCH": "1"},        # entropy chain per step
     {"VENC_ENTROPY_BATCH": "2"},

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h> /* types only: the library is bound at run time (venc_rccl.hip) */
 
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,12 +20,14 @@
 
 #include "../../include/venc_hip.h"
 #include "venc_kernels.hip"
+static_assert(offsetof(venc_mbinfo, cbp) % 4 == 0 && sizeof(venc_mbinfo) == 32, "luma_block_redo ORs a macroblock's luma cbp bits into the aligned word that starts at cbp");
 #include "venc_inter2.hip"
 #include "venc_me2.hip"
 #ifdef VENC_LEGACY_KERNELS
 #include "legacy/venc_me.hip"
 #endif
 #include "venc_me3.hip"
+#include "venc_me4.hip"
 #include "venc_subpel.hip"
 #include "venc_deblock.hip"
 #include "venc_cavlc_p.hip"
@@ -89,7 +92,9 @@ struct venc_ctx {
     int ev_luma_next;
     hipEvent_t ev_chroma;             /* the last chroma launch on stream 2 */
     int chroma_pending;               /* ev_chroma recorded and not yet waited for by the main stream */
-    int fuse_luma;                    /* 1 (default): luma transform inside k_me_pool / k_me_fix, chroma on stream 2; VENC_FUSE=0: k_inter_fused on the main chain */
+    int fuse_luma;                    /* 3 (default): luma transform inside k_me_pool / k_me_fix, the 4x4 blocks that hold a level left to extra blocks of the
+                                         k_me_fix launch, chroma on stream 2; 1: every block coded inside the search (round 2's shape); 2: chroma there too;
+                                         VENC_FUSE=0: k_inter_fused on the main chain */
     int fix_phase;                    /* which set of fix counters the next P step fills */
     /* rate control (cfg.rc_mode; spec/CODEC.md section 1a) */
     venc_geom g_idr;                  /* geometry with the quantiser constants of IDR pictures (base - 3) */
@@ -307,6 +312,9 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.intra_rec);
     (void)hipFree(c->b.intra_d0);
     (void)hipFree(c->b.fix_list);
+    (void)hipFree(c->b.nz_ids);
+    (void)hipFree(c->b.nz_cnt);
+    (void)hipFree(c->b.nz_rows);
     (void)hipFree(c->d_slice);
     (void)hipFree(c->d_slice_rows);
     (void)hipFree(c->d_row_slice);
@@ -443,8 +451,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
      * 2: chroma inside the search kernels too (waves 4-5 of P5): bit-exact, measured SLOWER -- the chroma samples come from memory
      * and their latency lengthens every block's tail while it holds a third of a CU's LDS (1080p 149 -> 141 Gpx/s, search alone
      * 85 -> 104 us; 2160p 196 -> 179) */
-    c->fuse_luma = getenv("VENC_FUSE") ? atoi(getenv("VENC_FUSE")) : 1;
-    if (c->fuse_luma < 0 || c->fuse_luma > 2) c->fuse_luma = 1;
+    c->fuse_luma = getenv("VENC_FUSE") ? atoi(getenv("VENC_FUSE")) : 3;
+    if (c->fuse_luma < 0 || c->fuse_luma > 3) c->fuse_luma = 3;
     for (int i = 0; i < VENC_RING; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
         c->side_step[i] = -1;
@@ -619,6 +627,12 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.intra_d0, G * nmb * 32 * 4));
     OPEN_OK(hipMemset(b.fix_count, 0, 2 * G * 4));
     OPEN_OK(hipMalloc(&b.fix_list, G * nmb * 4));
+    /* the segments of 4x4 luma blocks left to the k_me_fix launch: four transforming waves per 8 x 2-macroblock tile of the search */
+    b.nz_item_regions = 4 * ((g.mbw + T2_MBX - 1) / T2_MBX) * ((g.mbh + T2_MBY - 1) / T2_MBY);
+    OPEN_OK(hipMalloc(&b.nz_ids, (size_t)G * b.nz_item_regions * 64 * 4));
+    OPEN_OK(hipMalloc(&b.nz_rows, (size_t)G * b.nz_item_regions * 64 * 32));
+    OPEN_OK(hipMalloc(&b.nz_cnt, (size_t)G * b.nz_item_regions * 4));
+    OPEN_OK(hipMemset(b.nz_cnt, 0, (size_t)G * b.nz_item_regions * 4));
     OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
     OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
     if (g.subpel) {
@@ -942,7 +956,9 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         b.fix_count_next = c->b.fix_count + (size_t)(c->fix_phase ^ 1) * c->b.max_items;
         c->fix_phase ^= 1;
         const bool fuse = c->fuse_luma && c->me_mode == 0 && !c->inter_legacy && !g.subpel; /* (refinement sits between search and transform) */
-        const int fuse_arg = !fuse ? 0 : c->fuse_luma; /* 1: luma in the search kernels; 2: chroma too */
+        const int fuse_arg = !fuse ? 0 : c->fuse_luma; /* 3: luma in the search kernels, blocks with a level behind them; 1: all of luma inside; 2: chroma too */
+        int nz_regions = 0, nz_ntx = 1;
+        uint32_t nz_magic = 0;
         if (c->me_mode != 0) HIP_OK(hipMemsetAsync(b.fix_count_next, 0, (size_t)c->b.max_items * 4, s1));
         prof_begin(c, KID_ME, s1);
 #ifdef VENC_LEGACY_KERNELS
@@ -964,19 +980,38 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             const int gx = c->me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
             /* (VENC_ME_LDS_PAD=bytes of unused dynamic LDS per block: an experiment that holds the search at two blocks per CU) */
             static const int lds_pad = getenv("VENC_ME_LDS_PAD") ? atoi(getenv("VENC_ME_LDS_PAD")) : 0;
-            if (c->cfg.rc_mode)
+            /* k_me_pool4 (venc_me4.hip): the same search laid out for four blocks per CU; it transforms in the deferred form only */
+            /* VENC_ME_BLOCKS=3|4 pins the choice; default: four blocks per CU for steps below 200 000 macroblocks.  Measured, same box
+             * (gpurun_out/r03_defer2): ten 1080p items 146.6-147.5 -> 149.9 Gpx/s, ten 2160p items 201.3 -> 194.3 -- with all 512
+             * registers of every SIMD and the whole LDS in the search's hands the side chain (confined to 128 CUs at that size) waits
+             * for whole CUs: k_cavlc_p 4.2 -> 6.4 ms per pass. */
+            static const int me_blocks = getenv("VENC_ME_BLOCKS") ? atoi(getenv("VENC_ME_BLOCKS")) : 0;
+            const bool small_step = (long long)band_mbs * n_items < 200000;
+            const bool pool4 = (me_blocks == 4 || (me_blocks == 0 && small_step)) && (fuse_arg == 0 || fuse_arg == 3);
+            if (pool4 && c->cfg.rc_mode)
+                hipLaunchKernelGGL(k_me_pool4<true>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            else if (pool4)
+                hipLaunchKernelGGL(k_me_pool4<false>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            else if (c->cfg.rc_mode)
                 hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
             else
                 hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            if (fuse_arg == 3) nz_regions = 4 * ntx * nty, nz_ntx = ntx, nz_magic = tx_magic;
         }
         prof_end(c, s1);
         const bool flags_mbs = c->me_mode == 0 || c->me_mode == 3; /* these searches list macroblocks for the exhaustive search */
         if (flags_mbs) {
             prof_begin(c, KID_MEFIX, s1);
+            /* the blocks that code the 4x4 blocks P5 listed, first in dispatch order: per item one per NZ_RPB segments, each takes an
+             * equal share of the item's entries; every thread of such a block reads nz_rpt segment counts (a multiple of four) */
+            static const int nz_rpb = getenv("VENC_NZ_RPB") ? atoi(getenv("VENC_NZ_RPB")) : NZ_RPB;
+            const int nz_blocks = (nz_regions + nz_rpb - 1) / nz_rpb;
+            const int nz_rpt = (((nz_regions + 64 * FIX_WAVES - 1) / (64 * FIX_WAVES)) + 3) & ~3;
+            const size_t fix_lds = nz_blocks ? (size_t)64 * FIX_WAVES * nz_rpt : 0;
             if (c->cfg.rc_mode)
-                hipLaunchKernelGGL(k_me_fix<true>, dim3(FIX_BLOCKS, 1, n_items), dim3(64 * FIX_WAVES), 0, s1, g, b, S, fuse_arg);
+                hipLaunchKernelGGL(k_me_fix<true>, dim3(n_items, nz_blocks + FIX_BLOCKS, 1), dim3(64 * FIX_WAVES), fix_lds, s1, g, b, S, fuse_arg, nz_blocks, nz_regions, nz_rpt, nz_ntx, nz_magic);
             else
-                hipLaunchKernelGGL(k_me_fix<false>, dim3(FIX_BLOCKS, 1, n_items), dim3(64 * FIX_WAVES), 0, s1, g, b, S, fuse_arg);
+                hipLaunchKernelGGL(k_me_fix<false>, dim3(n_items, nz_blocks + FIX_BLOCKS, 1), dim3(64 * FIX_WAVES), fix_lds, s1, g, b, S, fuse_arg, nz_blocks, nz_regions, nz_rpt, nz_ntx, nz_magic);
             prof_end(c, s1);
         }
 #ifdef VENC_LEGACY_KERNELS
@@ -1014,7 +1049,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
              * needs nothing else (it reads luma only).  The chroma transforms of a batch of steps follow on the second
              * stream, one after the other (chroma reconstructions chain from step to step), ahead of the batch's entropy
              * chain and beside the next searches: ONE event hand-off per batch, none between the kernels of the main chain. */
-            chroma_deferred = c->fuse_luma < 2;
+            chroma_deferred = c->fuse_luma != 2;
             /* in-loop filter: luma here (the next search reads it); chroma behind its transform on the second stream */
             if (c->cfg.deblock) launch_deblock(c, s1, g, b, S, n_items, chroma_deferred ? 1 : 3);
         }

@@ -211,6 +211,91 @@ DEVFN void luma_block_code(const venc_geom &g, const venc_bufs &B, const venc_st
     }
 }
 
+/* DEFERRED BLOCKS (round 3, the shipped P5 of k_me_pool).  94-96 % of the clip's 4x4 blocks quantise to nothing, yet 80-94 % of
+ * the transforming waves hold at least one block that does not, so nearly every wave used to walk the ~280 instructions of
+ * quantisation ... reconstruction for three or four busy lanes.  Here a wave only decides: residual, forward transform and the
+ * exact zero test for all its blocks; a block without a level is finished (its reconstruction is the prediction); the few blocks
+ * WITH a level are listed -- entry = lane | cx << 6 | cy << 12 in the (tile, wave)'s own 64-entry segment, the count as a plain
+ * store: no atomic, nothing the wave waits for -- and coded by extra blocks of the k_me_fix launch that follows on the same stream
+ * (luma_nz_redo below), beside the exhaustive redo on a chip that launch leaves nearly idle.  Unlike the two in-kernel variants
+ * tried before (second pass behind a barrier; sixteen lanes per listed block) nothing is appended to the tail of the search block. */
+#define NZ_RPB 128 /* (tile, wave) segments per follow-up block of 256 threads (VENC_NZ_RPB): 16 / 64 blocks per 1080p / 2160p item; measured 32 / 64 / 128 */
+DEVFN void luma_block_defer(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, const uint32_t cq[4],
+                            const uint32_t pq[4], const venc_qparams &ql, uint32_t *seg, uint4 *seg_rows, uint32_t *seg_count, uint32_t mvbits) {
+    const int blk = lane & 15;
+    const int mx = mb % g.mbw, my = mb / g.mbw;
+    const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
+    int wstride;
+    uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
+    int res[16], w[16];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        res[4 * y] = byte_sub_byte<0>(cq[y], pq[y]);
+        res[4 * y + 1] = byte_sub_byte<1>(cq[y], pq[y]);
+        res[4 * y + 2] = byte_sub_byte<2>(cq[y], pq[y]);
+        res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
+    }
+    venc_fdct4(res, w);
+    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+    const bool nz = valid && !blk_all_zero<false>(w, ql);
+    const unsigned long long nzb = __ballot(nz);
+    if (valid) {
+        info->nnz[blk_y(blk) * 4 + blk_x(blk)] = 0; /* (a listed block's count and its bit of cbp come from the follow-up) */
+        if (!nz) {
+#pragma unroll
+            for (int y = 0; y < 4; y++) *(uint32_t *)(rec + (size_t)(py + y) * wstride + px) = pq[y];
+        }
+        if (blk == 0) {
+            info->cbp = 0;
+            info->flags = 0;
+        }
+    }
+    if (nz) { /* the entry and, beside it, the block's current and predicted rows: the follow-up reads them as two coalesced 16-byte pieces
+                 instead of twelve scattered dwords per lane (scattered, its loads took 25 us per 2160p launch: one cache line per lane) */
+        const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(nzb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)nzb, 0u));
+        seg[slot] = (uint32_t)lane | mvbits;
+        seg_rows[2 * slot] = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+        seg_rows[2 * slot + 1] = make_uint4(pq[0], pq[1], pq[2], pq[3]);
+    }
+    if (lane == 0) *seg_count = (uint32_t)__popcll(nzb);
+}
+
+/* one listed block, any lane: its current and predicted rows as the search left them beside the entry, everything from the residual
+ * to the stores; its bit of the macroblock's coded_block_pattern is OR-ed into the record's word (the search's P5 zeroed it; the
+ * chroma byte of that word is written by a later kernel of the side chain) */
+DEVFN void luma_block_redo(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int mx, int my, int blk, const uint4 cur4, const uint4 pred4,
+                           const venc_qparams &ql) {
+    const int mb = my * g.mbw + mx;
+    const int px = mx * 16 + blk_x(blk) * 4, py = my * 16 + blk_y(blk) * 4;
+    int wstride;
+    uint8_t *rec = rec_plane(B, g, S.parity, item, 0, wstride);
+    const uint32_t cq[4] = {cur4.x, cur4.y, cur4.z, cur4.w}, pq[4] = {pred4.x, pred4.y, pred4.z, pred4.w};
+    int res[16], w[16], lv[16], rr[16], nnz;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        res[4 * y] = byte_sub_byte<0>(cq[y], pq[y]);
+        res[4 * y + 1] = byte_sub_byte<1>(cq[y], pq[y]);
+        res[4 * y + 2] = byte_sub_byte<2>(cq[y], pq[y]);
+        res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
+    }
+    venc_fdct4(res, w);
+    blk_quant_res<false>(w, ql, ql.f_inter, 0, lv, rr, nnz);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        rr[4 * y] = venc_clip_u8(int_add_byte<0>(rr[4 * y], pq[y]));
+        rr[4 * y + 1] = venc_clip_u8(int_add_byte<1>(rr[4 * y + 1], pq[y]));
+        rr[4 * y + 2] = venc_clip_u8(int_add_byte<2>(rr[4 * y + 2], pq[y]));
+        rr[4 * y + 3] = venc_clip_u8(int_add_byte<3>(rr[4 * y + 3], pq[y]));
+    }
+    venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
+    if (nnz) {
+        store_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + blk * 16, lv);
+        atomicOr((uint32_t *)&info->cbp, 1u << (blk >> 2)); /* (cbp is the low byte of a 4-aligned word: static_assert in venc_hip.hip) */
+    }
+    info->nnz[blk_y(blk) * 4 + blk_x(blk)] = (uint8_t)nnz;
+    store_rec4x4(rec, wstride, px, py, rr);
+}
+
 /* luma transform of macroblock mb with vector (dx, dy), current and predicted samples fetched from memory */
 DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy,
                          const venc_qparams &ql) {

@@ -132,6 +132,12 @@ typedef struct {
     uint32_t *fix_list;         /* [G][nmb] their indices */
     unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
+    /* 4x4 luma blocks with a level, listed by the search's P5 for the extra blocks of the k_me_fix launch (venc_inter2.hip
+     * luma_block_defer): one 64-entry segment per (tile, transforming wave), entry = lane | cx << 6 | cy << 12 */
+    uint32_t *nz_ids;           /* [G][nz_item_regions][64] */
+    uint4 *nz_rows;             /* [G][nz_item_regions][64][2] the listed block's four current and four predicted rows (packed samples) */
+    uint32_t *nz_cnt;           /* [G][nz_item_regions] entries of each segment: written (also as 0) by every transforming wave of every P step */
+    int nz_item_regions;        /* segments per item: 4 x tiles of the whole picture */
     /* rate control: three sets of per-item sums of the best SADs rotate between P steps -- the search of a step reads the
      * previous step's, adds to its own (k_me_fix corrects it for the macroblocks it redoes) and zeroes the next one's --
      * and the QP each (step, item) was coded at, in the step ring, for the kernels that run later (chroma, entropy) */

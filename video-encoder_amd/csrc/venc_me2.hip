@@ -67,21 +67,111 @@ DEVFN uint2 pk4_sub(uint2 a, uint2 b) { return make_uint2(a.x - b.x, a.y - b.y);
                        lane instead of 24 and 576, no idle lanes: 17 -> 28 us per launch, 1080p 151 -> 143 Gpx/s.) */
 #define FIX_WAVES 4
 
+/* The follow-up of luma_block_defer (venc_inter2.hip): the listed 4x4 blocks of one item, BALANCED over the item's nz_blocks
+ * blocks of 256 threads.  Listed blocks cluster (an occlusion fills its segments, most segments are empty): dealt out segment
+ * by segment, the block that drew the cluster looped sixteen times while the others idled -- the launch took 33 us whatever the
+ * picture size.  So every block reads ALL segment counts of its item (rpt per thread, as uint4), the block scans them, and block
+ * b takes entries [b, b + 1) x ceil(total / nz_blocks) of the item's concatenated lists: thread k of a round finds its entry's
+ * thread-segment by binary search over the 256 partial sums and walks that segment's counts (bytes in LDS).
+ *   s_part: 256 exclusive partial sums + the total; s_wsum: 4 wave totals; s_cnt8: 256 x rpt counts as bytes (dynamic LDS) */
+DEVFN void luma_nz_redo(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int nzblock, int nz_blocks, int regions, int rpt, int ntx,
+                        uint32_t tx_magic, const venc_qparams &ql, uint32_t *s_part, uint32_t *s_wsum, uint32_t *s_cnt32) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ibase = (size_t)item * B.nz_item_regions;
+    const int rpt4 = rpt >> 2;
+    uint32_t sum = 0;
+    for (int q0 = 0; q0 < rpt4; q0 += 8) { /* eight quads per round, all loads of a round in flight together (one round up to 2160p) */
+        uint4 cc[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int r = tid * rpt + 4 * (q0 + u); /* (regions and rpt are multiples of four: a quad is inside or outside) */
+            cc[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (q0 + u < rpt4 && r < regions) cc[u] = *(const uint4 *)(B.nz_cnt + ibase + r);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            uint4 c = cc[u];
+            c.x = min(c.x, 64u), c.y = min(c.y, 64u), c.z = min(c.z, 64u), c.w = min(c.w, 64u);
+            sum += c.x + c.y + c.z + c.w;
+            if (q0 + u < rpt4) s_cnt32[tid * rpt4 + q0 + u] = c.x | (c.y << 8) | (c.z << 16) | (c.w << 24);
+        }
+    }
+    const uint32_t incl = wave_scan_incl(sum);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < FIX_WAVES; w++) {
+        const uint32_t ws = s_wsum[w];
+        woff += w < wave ? ws : 0u;
+        total += ws;
+    }
+    s_part[tid] = woff + incl - sum;
+    if (tid == 0) s_part[256] = total;
+    __syncthreads();
+    const uint32_t chunk = (total + (uint32_t)nz_blocks - 1u) / (uint32_t)nz_blocks;
+    const uint32_t lo = (uint32_t)nzblock * chunk, hi = min(total, lo + chunk);
+    for (uint32_t k = lo + (uint32_t)tid; k < hi; k += 64 * FIX_WAVES) {
+        int t = 0; /* the last thread-segment that starts at or before entry k (it is not empty: the next one starts behind k) */
+#pragma unroll
+        for (int step = 128; step; step >>= 1)
+            if (s_part[t + step] <= k) t += step;
+        uint32_t rem = k - s_part[t];
+        int r = t * rpt;
+        for (int q = 0; q < rpt4; q++) { /* walk the segment's counts: rem < their sum */
+            const uint32_t wd = s_cnt32[t * rpt4 + q];
+            const uint32_t c0 = wd & 255u, c1 = (wd >> 8) & 255u, c2 = (wd >> 16) & 255u, c3 = wd >> 24;
+            if (rem < c0 + c1 + c2 + c3) {
+                if (rem >= c0) {
+                    rem -= c0, r++;
+                    if (rem >= c1) {
+                        rem -= c1, r++;
+                        if (rem >= c2) rem -= c2, r++;
+                    }
+                }
+                break;
+            }
+            rem -= c0 + c1 + c2 + c3, r += 4;
+        }
+        const size_t slot = (ibase + r) * 64 + rem;
+        const uint32_t e = B.nz_ids[slot];
+        const uint4 cur4 = B.nz_rows[2 * slot], pred4 = B.nz_rows[2 * slot + 1];
+        const int tile = r >> 2;
+        const int m = (r & 3) * 4 + (int)((e >> 4) & 3u), blk = (int)(e & 15u);
+        const int ty = tx_magic ? (int)__umulhi((uint32_t)tile, tx_magic) : tile, tx = tile - ty * ntx;
+        const int mx = tx * T2_MBX + (m & (T2_MBX - 1)), my = S.row0 + ty * T2_MBY + (m >> 3);
+        luma_block_redo(g, B, S, item, mx, my, blk, cur4, pred4, ql);
+    }
+}
+
 template <bool RC> /* rate-control variant, as k_me_pool's */
-__global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_bufs B, venc_step S, int fuse_luma) {
+__global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_bufs B, venc_step S, int fuse_luma, int nz_blocks, int nz_regions, int nz_rpt, int ntx, uint32_t tx_magic) {
     __shared__ uint32_t s_win[(48 + 4) * FIX_WD];
     __shared__ uint32_t s_cur[16 * 4];
     __shared__ uint32_t s_best[FIX_WAVES];
     __shared__ int s_mv[2];
-    const int item = blockIdx.z, tid = threadIdx.x;
+    /* Grid = (items, nz_blocks + FIX_BLOCKS): the item runs fastest in dispatch order, so that the few blocks with work -- the
+     * first `count` redo blocks of every item, the follow-up blocks -- are all resident at once instead of queueing behind
+     * the 256 redo blocks per item that only load their count and leave (three blocks of this kernel fit a CU). */
+    const int item = blockIdx.x, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    /* the first nz_blocks rows of the grid (fuse_luma == 3): the 4x4 blocks the search's P5 listed instead of coding them
+     * (venc_inter2.hip luma_block_defer) -- no part in the exhaustive redo or in the closing of the picture's SAD sum */
+    if ((int)blockIdx.y < nz_blocks) {
+        venc_qparams qln = g.ql, qcn = g.qc;
+        if (RC) step_qparams(g, B, S, item, qln, qcn);
+        extern __shared__ uint32_t s_dyn[]; /* 256 x nz_rpt bytes: the item's segment counts */
+        luma_nz_redo(g, B, S, item, (int)blockIdx.y, nz_blocks, nz_regions, nz_rpt, ntx, tx_magic, qln, s_win, s_win + 260, s_dyn);
+        return;
+    }
+    const uint32_t fb = blockIdx.y - (uint32_t)nz_blocks; /* redo block of this item */
     /* the block's first list entry is fetched together with the count (it is meaningful only below the count): one memory
      * round trip less on a kernel whose whole cost is latency */
-    const uint32_t first_mb = B.fix_list[(size_t)item * g.nmb + min((int)blockIdx.x, g.nmb - 1)];
+    const uint32_t first_mb = B.fix_list[(size_t)item * g.nmb + min((int)fb, g.nmb - 1)];
     const uint32_t count = min(B.fix_count[item], (uint32_t)g.nmb);
     /* blocks with a listed macroblock (under rate control: block 0 too when nothing is listed: somebody has to close the sum) */
-    const uint32_t reporting = RC ? max(1u, min(count, (uint32_t)gridDim.x)) : count;
-    if (blockIdx.x >= reporting) return;
+    const uint32_t reporting = RC ? max(1u, min(count, (uint32_t)FIX_BLOCKS)) : count;
+    if (fb >= reporting) return;
     int rstride, cstride, pw, ph;
     const uint8_t *ref = rec_plane(B, g, S.ref, item, 0, rstride);
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], 0, cstride, pw, ph);
@@ -92,9 +182,9 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     /* the ranks of this lane's candidates do not depend on the macroblock: fetched before anything else, used last */
     uint32_t rk[FIX_NDY];
 #pragma unroll
-    for (int k = 0; k < FIX_NDY; k++) rk[k] = (blockIdx.x < count && dy0 + k <= 32 && lane < 33) ? (uint32_t)B.me_rank[(dy0 + k) * 33 + dxi] : 0x7ffu;
-    for (uint32_t i = blockIdx.x; i < count; i += gridDim.x) {
-        const int mb = (int)(i == blockIdx.x ? first_mb : B.fix_list[(size_t)item * g.nmb + i]);
+    for (int k = 0; k < FIX_NDY; k++) rk[k] = (fb < count && dy0 + k <= 32 && lane < 33) ? (uint32_t)B.me_rank[(dy0 + k) * 33 + dxi] : 0x7ffu;
+    for (uint32_t i = fb; i < count; i += FIX_BLOCKS) {
+        const int mb = (int)(i == fb ? first_mb : B.fix_list[(size_t)item * g.nmb + i]);
         const int mx = mb % g.mbw, my = mb / g.mbw;
         const int x0 = mx * 16, y0 = my * 16;
         __syncthreads();
@@ -192,7 +282,7 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
                 }
                 luma_block_code(g, B, S, item, lane, mb, lane < 16, cq, pq, qlf);
             }
-            if (fuse_luma > 1 && tid >= 64 && tid < 128) /* its chroma transform: lanes 0-7 of wave 1 */
+            if (fuse_luma == 2 && tid >= 64 && tid < 128) /* its chroma transform: lanes 0-7 of wave 1 */
                 inter_chroma_mb(g, B, S, item, lane, mb, lane < 8, s_mv[0] - 16, s_mv[1] - 16, qcf);
         }
     }

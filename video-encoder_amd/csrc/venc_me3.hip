@@ -532,7 +532,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             if (l7 == 0 && tot) atomicAdd(&B.sad_cur[item], (unsigned long long)tot);
         }
     }
-    if (fuse_luma > 1 && threadIdx.x >= 256 && threadIdx.x < 384) {
+    if (fuse_luma == 2 && threadIdx.x >= 256 && threadIdx.x < 384) {
         /* ... and the chroma transform of the same macroblocks on waves 4 and 5, which would otherwise have left: 8 lanes
          * per macroblock, samples from memory (the chroma planes are not in LDS), venc_inter2.hip inter_chroma_mb.  No chroma
          * launch is left on either stream. */
@@ -559,6 +559,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             cq[y] = cp[y * T3_CW];
             pq[y] = __builtin_amdgcn_alignbyte(wp[y * T2_WD + 1], wp[y * T2_WD], sh);
         }
-        luma_block_code(g, B, S, item, t5 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, cq, pq, ql5);
+        if (fuse_luma == 3) {
+            /* the shipped path: decide only -- blocks without a level are finished here, the few with one are listed in this
+             * (tile, wave)'s segment for the extra blocks of the k_me_fix launch (venc_inter2.hip luma_block_defer) */
+            const size_t region = (size_t)item * B.nz_item_regions + (size_t)tile * 4 + (size_t)(t5 >> 6);
+            luma_block_defer(g, B, S, item, t5 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, cq, pq, ql5, B.nz_ids + region * 64, B.nz_rows + region * 128, B.nz_cnt + region, (bcx << 6) | (bcy << 12));
+        } else
+            luma_block_code(g, B, S, item, t5 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, cq, pq, ql5);
     }
 }
