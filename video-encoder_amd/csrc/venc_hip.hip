@@ -30,6 +30,7 @@ static_assert(offsetof(venc_mbinfo, cbp) % 4 == 0 && sizeof(venc_mbinfo) == 32, 
 #include "venc_me4.hip"
 #include "venc_subpel.hip"
 #include "venc_deblock.hip"
+#include "venc_deblock2.hip"
 #include "venc_cavlc_p.hip"
 #include "venc_intra2.hip"
 #include "venc_synth.h"
@@ -227,8 +228,21 @@ static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, cons
     static const int cap = getenv("VENC_DBK_WAVES") ? atoi(getenv("VENC_DBK_WAVES")) : DBK_MAX_WAVES; /* (diagnostic: fewer rows at a time) */
     const int wmax = cap >= 1 && cap < DBK_MAX_WAVES ? cap : DBK_MAX_WAVES;
     const int waves = max_rows < wmax ? max_rows : wmax;
+    /* k_deblock_ls (venc_deblock2.hip): the rows of a slice in lock-step, four rows per wave; VENC_DBK=strip: the first kernel
+     * (one wave per row, progress flags) */
+    static const bool strip = getenv("VENC_DBK") && !strcmp(getenv("VENC_DBK"), "strip");
     prof_begin(c, KID_DEBLOCK, st);
-    hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), (size_t)waves * sizeof(dbk_strip), st, g, b, S, planes);
+    if (strip)
+        hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), (size_t)waves * sizeof(dbk_strip), st, g, b, S, planes);
+    else {
+        const int lw = (max_rows + 3) / 4 < DL_MAX_WAVES / 2 ? (max_rows + 3) / 4 : DL_MAX_WAVES / 2; /* filter waves; as many helper waves */
+        const dim3 grid(S.slice1 - S.slice0, 1, n_items), block(2 * 64 * lw);
+        const size_t lds = (size_t)4 * lw * sizeof(dl_row);
+        static const int diag = getenv("VENC_DL_DIAG") ? atoi(getenv("VENC_DL_DIAG")) : 0; /* (diagnostic: parts of a step left out, pictures then wrong) */
+        if (planes == 1) hipLaunchKernelGGL(k_deblock_ls<1>, grid, block, lds, st, g, b, S, diag);
+        else if (planes == 2) hipLaunchKernelGGL(k_deblock_ls<2>, grid, block, lds, st, g, b, S, diag);
+        else hipLaunchKernelGGL(k_deblock_ls<3>, grid, block, lds, st, g, b, S, diag);
+    }
     prof_end(c, st);
 }
 /* the chroma transform of the last P step runs on the second stream: anything on the main stream that touches chroma
