@@ -53,7 +53,11 @@ grep -o '"equals_one_rank_bitstream": [a-z]*' $O/bench_streams2.json $O/bench_st
 bash tools/me_phase_pmc.sh ${1:-final}/phase 1080p > /dev/null 2>&1; cp $O/phase/me_phase_1080p.txt $O/ 2>/dev/null
 tools/valu_ubench > $O/valu_ubench.txt 2>&1
 tools/h2d_ubench > $O/h2d_ubench.txt 2>&1
-bash tools/r03_dbk_waves.sh ${1:-final}/dbkw > $O/deblock_waves_per_block.txt 2>&1
+tools/ifetch_ubench > $O/ifetch_ubench.txt 2>&1
+# same-box A/B of the round's kernels against the shapes they replace
+bash tools/r03_defer2.sh > $O/ab_search_variants.txt 2>&1
+bash tools/r03_dbk2.sh > $O/ab_deblock_kernels.txt 2>&1
+bash tools/dbk_step_budget.sh ${1:-final}/dbkb > $O/deblock_step_budget.txt 2>&1
 bash tools/r03_dbk_pmc.sh ${1:-final}/dbkpmc libvenc_hip.so > $O/deblock_sq_counters.txt 2>&1
 # keep the merged output small: the raw traces stay on the box
 for d in $O/pmcf_* $O/pmcw_* $O/stats_* $O/sq_1080p $O/sq_2160p; do [ -d "$d" ] && find $d -name "*agent_info.csv" -delete; done

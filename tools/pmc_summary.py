@@ -18,6 +18,8 @@ def per_kernel(d, counter):
         if name.startswith("void "):
             name = name[5:]
         name = name.split("<")[0]
+        if name == "k_me_pool4":  # the search on four blocks per CU (steps below 200 000 macroblocks): reported as the search kernel
+            name = "k_me_pool"
         acc[name][0] += float(r["Counter_Value"])
         acc[name][1] += 1
     return acc
