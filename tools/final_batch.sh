@@ -1,11 +1,15 @@
 #!/bin/bash
-# Measurement batch for profiles/: run on the GPU box from the repo root:  bash tools/final_batch.sh <tag>
+# Measurement batch for profiles/: run on the GPU box from the repo root:  bash tools/final_batch.sh <tag> [a|b]
+# (two halves, each inside one gpurun call's time limit: a = PMC traffic, bench lines, tool matrix, kernel stats, SQ counters;
+#  b = slice-band and two-rank runs, phase budgets, microbenchmarks, the round's same-box A/B runs)
 # PMC passes are separate rocprofv3 runs (counters never together with --stats); the program itself follows "--".
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/${1:-final}
 mkdir -p $O
 cd $R
 Q="--no-extras --cpu-frames 0"
+PART=${2:-ab}
+if [[ $PART == *a* ]]; then
 cd /tmp; export TMPDIR=/tmp
 for wl in 1080p 2160p; do
   timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmcf_$wl -- python3 $R/bench.py --workload $wl --steps 1 --warmup 0 $Q --no-profile > $O/pmcf_$wl.log 2>&1 &&
@@ -42,6 +46,8 @@ done
 cd $R
 for wl in 1080p 2160p; do python3 tools/sq_summary.py $O/sq_$wl $wl profiles/sq_counters.json > $O/sq_counters_${wl}_isolated.txt 2> $O/sq_summary_$wl.err; done
 cp profiles/sq_counters.json $O/
+fi
+if [[ $PART == *b* ]]; then
 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --mode slices --workload 2160p $Q > $O/bench_slices1.json 2> $O/bench_slices1.err; cut -c1-240 $O/bench_slices1.json
 # two ranks on the one GPU (gloo rehearsal of the N > 1 run: bench.py starts its own ranks; the line carries the config-5 leg as slices_2160p)
 timeout -k 10 500 python bench.py --gpus 2 --device 0 --backend gloo --steps 3 --warmup 1 $Q --slices-steps 2 > $O/bench_streams2.json 2> $O/bench_streams2.err
@@ -59,6 +65,7 @@ bash tools/r03_defer2.sh > $O/ab_search_variants.txt 2>&1
 bash tools/r03_dbk2.sh > $O/ab_deblock_kernels.txt 2>&1
 bash tools/dbk_step_budget.sh ${1:-final}/dbkb > $O/deblock_step_budget.txt 2>&1
 bash tools/r03_dbk_pmc.sh ${1:-final}/dbkpmc libvenc_hip.so > $O/deblock_sq_counters.txt 2>&1
+fi
 # keep the merged output small: the raw traces stay on the box
 for d in $O/pmcf_* $O/pmcw_* $O/stats_* $O/sq_1080p $O/sq_2160p; do [ -d "$d" ] && find $d -name "*agent_info.csv" -delete; done
 du -sh $O
