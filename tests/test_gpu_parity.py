@@ -307,7 +307,6 @@ def test_intra_three_kernels_equal_the_wavefront_kernel(venc, legacy_lib, w, h, 
 @pytest.mark.parametrize("env", [
     {"VENC_FUSE": "0"},                 # luma + chroma transform as k_inter_fused on the main chain (round 1's shape)
     {"VENC_FUSE": "1"},                 # every luma block coded inside the search kernels (round 2's shape; default: blocks with a level behind them)
-    {"VENC_FUSE": "2"},                 # chroma transform inside the search kernels too
     {"VENC_ME_BLOCKS": "3"},            # the search on three blocks per CU (k_me_pool) with the deferred transform
     {"VENC_ME_BLOCKS": "4"},            # ... on four (k_me_pool4), whatever the step size
     {"VENC_NZ_RPB": "4"},               # one follow-up block per search tile: many blocks, every share small

@@ -94,7 +94,7 @@ struct venc_ctx {
     hipEvent_t ev_chroma;             /* the last chroma launch on stream 2 */
     int chroma_pending;               /* ev_chroma recorded and not yet waited for by the main stream */
     int fuse_luma;                    /* 3 (default): luma transform inside k_me_pool / k_me_fix, the 4x4 blocks that hold a level left to extra blocks of the
-                                         k_me_fix launch, chroma on stream 2; 1: every block coded inside the search (round 2's shape); 2: chroma there too;
+                                         k_me_fix launch, chroma on stream 2; 1: every block coded inside the search (round 2's shape);
                                          VENC_FUSE=0: k_inter_fused on the main chain */
     int fix_phase;                    /* which set of fix counters the next P step fills */
     /* rate control (cfg.rc_mode; spec/CODEC.md section 1a) */
@@ -466,7 +466,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
      * and their latency lengthens every block's tail while it holds a third of a CU's LDS (1080p 149 -> 141 Gpx/s, search alone
      * 85 -> 104 us; 2160p 196 -> 179) */
     c->fuse_luma = getenv("VENC_FUSE") ? atoi(getenv("VENC_FUSE")) : 3;
-    if (c->fuse_luma < 0 || c->fuse_luma > 3) c->fuse_luma = 3;
+    if (c->fuse_luma < 0 || c->fuse_luma > 3 || c->fuse_luma == 2) c->fuse_luma = 3; /* (2, the chroma transform inside the search kernels too, was measured slower in round 2 and left the sources in round 3) */
     for (int i = 0; i < VENC_RING; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->ev_side[i], hipEventDisableTiming));
         c->side_step[i] = -1;
@@ -970,7 +970,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         b.fix_count_next = c->b.fix_count + (size_t)(c->fix_phase ^ 1) * c->b.max_items;
         c->fix_phase ^= 1;
         const bool fuse = c->fuse_luma && c->me_mode == 0 && !c->inter_legacy && !g.subpel; /* (refinement sits between search and transform) */
-        const int fuse_arg = !fuse ? 0 : c->fuse_luma; /* 3: luma in the search kernels, blocks with a level behind them; 1: all of luma inside; 2: chroma too */
+        const int fuse_arg = !fuse ? 0 : c->fuse_luma; /* 3: luma in the search kernels, blocks with a level behind them; 1: all of luma inside */
         int nz_regions = 0, nz_ntx = 1;
         uint32_t nz_magic = 0;
         if (c->me_mode != 0) HIP_OK(hipMemsetAsync(b.fix_count_next, 0, (size_t)c->b.max_items * 4, s1));
@@ -1063,7 +1063,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
              * needs nothing else (it reads luma only).  The chroma transforms of a batch of steps follow on the second
              * stream, one after the other (chroma reconstructions chain from step to step), ahead of the batch's entropy
              * chain and beside the next searches: ONE event hand-off per batch, none between the kernels of the main chain. */
-            chroma_deferred = c->fuse_luma != 2;
+            chroma_deferred = true;
             /* in-loop filter: luma here (the next search reads it); chroma behind its transform on the second stream */
             if (c->cfg.deblock) launch_deblock(c, s1, g, b, S, n_items, chroma_deferred ? 1 : 3);
         }

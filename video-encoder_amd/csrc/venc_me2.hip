@@ -282,8 +282,6 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
                 }
                 luma_block_code(g, B, S, item, lane, mb, lane < 16, cq, pq, qlf);
             }
-            if (fuse_luma == 2 && tid >= 64 && tid < 128) /* its chroma transform: lanes 0-7 of wave 1 */
-                inter_chroma_mb(g, B, S, item, lane, mb, lane < 8, s_mv[0] - 16, s_mv[1] - 16, qcf);
         }
     }
     /* Rate control: the picture's SAD sum is final once every block of this launch has made its corrections.  The block that

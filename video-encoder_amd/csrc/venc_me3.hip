@@ -516,11 +516,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * the two luma planes from memory and costs the main chain no launch of its own. ---- */
     /* the pictures' quantiser constants: fixed, or those of the QP chosen from the previous picture's SAD sum
      * (spec/CODEC.md section 1a; one table load -- the division of the rule is done once per picture, in k_me_fix) */
-    venc_qparams ql5 = g.ql, qc5 = g.qc;
+    venc_qparams ql5 = g.ql;
     if (RC) {
         const int qp5 = __builtin_amdgcn_readfirstlane(S.rc_history ? B.qp_cur[item] : S.qp_base); /* uniform: scalar table loads */
         ql5 = qparams_uniform(B.qtab + qp5);
-        qc5 = qparams_uniform(B.qtab + venc_chroma_qp(qp5));
         if (threadIdx.x >= 448) { /* wave 7 has nothing to do in P5: this tile's share of the picture's SAD sum, one atomic per block */
             const int l7 = threadIdx.x - 448;
             uint32_t sad = 0;
@@ -531,16 +530,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(sad), 63);
             if (l7 == 0 && tot) atomicAdd(&B.sad_cur[item], (unsigned long long)tot);
         }
-    }
-    if (fuse_luma == 2 && threadIdx.x >= 256 && threadIdx.x < 384) {
-        /* ... and the chroma transform of the same macroblocks on waves 4 and 5, which would otherwise have left: 8 lanes
-         * per macroblock, samples from memory (the chroma planes are not in LDS), venc_inter2.hip inter_chroma_mb.  No chroma
-         * launch is left on either stream. */
-        const int t6 = threadIdx.x - 256, m = t6 >> 3;
-        const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
-        const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] <= (uint32_t)T3_CAP;
-        const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
-        inter_chroma_mb(g, B, S, item, t6 & 63, min(my5, g.mbh - 1) * g.mbw + min(mx5, g.mbw - 1), ok, (int)bcx - 16, (int)bcy - 16, qc5);
     }
     if (fuse_luma && threadIdx.x < 256) {
         const int t5 = threadIdx.x, m = t5 >> 4, blk = t5 & 15;

@@ -340,15 +340,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             wcnt = 0, mycnt = 0; /* the segment is rebuilt */
         }
-        if (l32 == 0) s_ovf[hw] = mycnt; /* > T3_CAP: the macroblock is left to k_me_fix */
-        if (lane == 0) s_wcnt[tid >> 6] = wcnt;
+        {   /* (indices from an opaque copy of the thread id: kept across the passes, the address of s_ovf[hw] was spilled) */
+            uint32_t tidc = threadIdx.x;
+            asm volatile("" : "+v"(tidc));
+            if ((tidc & 31u) == 0u) s_ovf[tidc >> 5] = mycnt; /* > T3_CAP: the macroblock is left to k_me_fix */
+            if ((tidc & 63u) == 0u) s_wcnt[tidc >> 6] = wcnt;
+        }
     }
     __syncthreads();
     if (S.me_stop == 5) {
         if (l32 == 0 && mb_valid) B.mvsad[(size_t)item * g.nmb + (size_t)my * g.mbw + mx] = (uint32_t)(s_best[hw] >> 22) << 16;
         return;
     }
-    /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves (as venc_me3; ranks from memory) ---- */
+    /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves (as venc_me3; ranks from memory) ----
+     * From here on the lane indices are re-derived from an opaque copy of the thread id: carried across P4a, four of them were
+     * spilled (scratch stores and reloads of every thread: 42 MB of writes per 1080p launch in the PMC counters, and a memory round
+     * trip at the head of every block's tail). */
+    uint32_t tidb = threadIdx.x;
+    asm volatile("" : "+v"(tidb));
+    const int laneb = (int)(tidb & 63u);
     {
         const uint4 wa = *(const uint4 *)&s_wcnt[0], wb = *(const uint4 *)&s_wcnt[4];
         const uint32_t wc[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int j = 0; j < 8; j++) pre[j + 1] = pre[j] + wc[j];
         const uint32_t total = pre[8];
-        for (uint32_t k = (uint32_t)(tid >> 4); k < ((total + 31u) & ~31u); k += 32u) {
+        for (uint32_t k = tidb >> 4; k < ((total + 31u) & ~31u); k += 32u) {
             uint32_t start = 0, sbase = 0;
 #pragma unroll
             for (int j = 1; j < 8; j++) {
@@ -374,14 +384,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint32_t rk = rank[need ? ci : 0];
             const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
             const int ecol = need ? (ehw & (T2_MBX - 1)) * 16 : 0, erow = need ? (ehw >> 3) * 16 : 0;
-            const uint32_t sad = me3_quarter_sad(s_win, s_cur, ecol, erow, lane, cx, cy);
-            if (need && (lane & 15) == 15) atomicMin(&s_best[ehw], ((unsigned long long)((sad << 11) | rk) << 11) | (uint32_t)ci);
+            const uint32_t sad = me3_quarter_sad(s_win, s_cur, ecol, erow, laneb, cx, cy);
+            if (need && (laneb & 15) == 15) atomicMin(&s_best[ehw], ((unsigned long long)((sad << 11) | rk) << 11) | (uint32_t)ci);
         }
     }
     __syncthreads();
     /* the tile's results leave from one wave (lane = macroblock) */
-    if ((threadIdx.x >> 6) == 6) {
-        const int m = (int)(threadIdx.x & 63u);
+    if ((tidb >> 6) == 6) {
+        const int m = laneb;
         const int mxo = tx * T2_MBX + (m & (T2_MBX - 1)), myo = S.row0 + ty * T2_MBY + ((m >> 3) & (T2_MBY - 1));
         if (m < T2_MBX * T2_MBY && mxo < g.mbw && myo < S.row1) {
             const size_t mbo = (size_t)item * g.nmb + (size_t)myo * g.mbw + mxo;
@@ -402,8 +412,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     if (RC) {
         const int qp5 = __builtin_amdgcn_readfirstlane(S.rc_history ? B.qp_cur[item] : S.qp_base);
         ql5 = qparams_uniform(B.qtab + qp5);
-        if (threadIdx.x >= 448) { /* wave 7: this tile's share of the picture's SAD sum, one atomic per block */
-            const int l7 = threadIdx.x - 448;
+        if (tidb >= 448) { /* wave 7: this tile's share of the picture's SAD sum, one atomic per block */
+            const int l7 = (int)tidb - 448;
             uint32_t sad = 0;
             if (l7 < T2_MBX * T2_MBY) {
                 const int mx7 = tx * T2_MBX + (l7 & (T2_MBX - 1)), my7 = S.row0 + ty * T2_MBY + (l7 >> 3);
@@ -413,8 +423,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (l7 == 0 && tot) atomicAdd(&B.sad_cur[item], (unsigned long long)tot);
         }
     }
-    if (fuse_luma && threadIdx.x < 256) {
-        const int t5 = threadIdx.x, m = t5 >> 4, blk = t5 & 15;
+    if (fuse_luma && tidb < 256) {
+        const int t5 = (int)tidb, m = t5 >> 4, blk = t5 & 15;
         const int mcol0 = (m & (T2_MBX - 1)) * 16, mrow0 = (m >> 3) * 16;
         const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
         const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] <= (uint32_t)T3_CAP;
