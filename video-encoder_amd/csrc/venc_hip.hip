@@ -421,7 +421,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
          * CUs; the search beside it 330 -> 297 us, +4 % on the pass).  At 1080p x 10 items the confined chain would be
          * the longer one (measured: -10 %), so no mask there.  VENC_ENTROPY_CUS=0 / =n overrides. */
         const char *e = getenv("VENC_ENTROPY_CUS");
-        const int ncu = e ? atoi(e) : ((long long)g.nmb * cfg->max_items >= 200000 ? 128 : 0);
+        const int ncu = e ? atoi(e) : ((long long)g.nmb * cfg->max_items >= 200000 ? 192 : 0); /* (round 3, with the search on four blocks per CU: 2160p x 10 items 206.9 Gpx/s unmasked, 201.0 on 256 (a masked queue), 211.8 on 192, 143.6 on 64; round 2 with three blocks per CU chose 128) */
         hipDeviceProp_t prop;
         OPEN_OK(hipGetDeviceProperties(&prop, cfg->device));
         if (ncu >= 8 && ncu < prop.multiProcessorCount) {
@@ -995,13 +995,12 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             /* (VENC_ME_LDS_PAD=bytes of unused dynamic LDS per block: an experiment that holds the search at two blocks per CU) */
             static const int lds_pad = getenv("VENC_ME_LDS_PAD") ? atoi(getenv("VENC_ME_LDS_PAD")) : 0;
             /* k_me_pool4 (venc_me4.hip): the same search laid out for four blocks per CU; it transforms in the deferred form only */
-            /* VENC_ME_BLOCKS=3|4 pins the choice; default: four blocks per CU for steps below 200 000 macroblocks.  Measured, same box
-             * (gpurun_out/r03_defer2): ten 1080p items 146.6-147.5 -> 149.9 Gpx/s, ten 2160p items 201.3 -> 194.3 -- with all 512
-             * registers of every SIMD and the whole LDS in the search's hands the side chain (confined to 128 CUs at that size) waits
-             * for whole CUs: k_cavlc_p 4.2 -> 6.4 ms per pass. */
-            static const int me_blocks = getenv("VENC_ME_BLOCKS") ? atoi(getenv("VENC_ME_BLOCKS")) : 0;
-            const bool small_step = (long long)band_mbs * n_items < 200000;
-            const bool pool4 = (me_blocks == 4 || (me_blocks == 0 && small_step)) && (fuse_arg == 0 || fuse_arg == 3);
+            /* VENC_ME_BLOCKS=3 selects k_me_pool (three blocks per CU); default: k_me_pool4.  Same box, ten items per launch
+             * (gpurun_out/r03_defer2, r03_cus): 1080p 150.6 -> 158.2 Gpx/s; 2160p 206.4 -> 206.9, and 211.8 with the side chain on
+             * 192 CUs (the default mask at that size): with every register and the whole LDS of a CU in the search's hands the side
+             * chain waits for whole CUs wherever it may run. */
+            static const int me_blocks = getenv("VENC_ME_BLOCKS") ? atoi(getenv("VENC_ME_BLOCKS")) : 4;
+            const bool pool4 = me_blocks != 3 && (fuse_arg == 0 || fuse_arg == 3);
             if (pool4 && c->cfg.rc_mode)
                 hipLaunchKernelGGL(k_me_pool4<true>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
             else if (pool4)
