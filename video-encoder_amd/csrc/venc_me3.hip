@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[8]; /* entries in each wave's pool segment */
     __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
+    __shared__ int s_q[sizeof(venc_qparams) / sizeof(int)]; /* rate control: the picture's quantiser constants, fetched in P0 for P5 */
     __shared__ __attribute__((aligned(8))) uint32_t s_c8[T2_MBX * T2_MBY][2]; /* per macroblock: TL | BL << 16, TR | BR << 16 (8x8 sums of the current pixels) */
     __shared__ __attribute__((aligned(4))) uint16_t s_rank[VENC_ME_CANDS + 1];
     uint2 *const s_h8 = (uint2 *)s_hv; /* T2_WR * T2_HG uint2 = 19968 B of the 30576 */
@@ -207,6 +208,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         ((uint32_t *)s_rank)[tid] = rk0;
         if (tid + 512 < 545) ((uint32_t *)s_rank)[tid + 512] = rk1;
         if (l32 == 0) s_prev[hw] = prev_early;
+        if (RC && tid < (int)(sizeof(venc_qparams) / sizeof(int))) {
+            /* (two dependent loads -- the picture's QP, then its row of the table -- issued here, beside the window's, instead of at the
+             * head of P5 where every block waited for them: the rate-control variant took 85 us alone where the fixed-QP one takes 74) */
+            const int qp0 = S.rc_history ? B.qp_cur[item] : S.qp_base;
+            s_q[tid] = ((const int *)(B.qtab + qp0))[tid];
+        }
     }
     __syncthreads();
     if (S.me_stop == 1) return;
@@ -518,8 +525,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * (spec/CODEC.md section 1a; one table load -- the division of the rule is done once per picture, in k_me_fix) */
     venc_qparams ql5 = g.ql;
     if (RC) {
-        const int qp5 = __builtin_amdgcn_readfirstlane(S.rc_history ? B.qp_cur[item] : S.qp_base); /* uniform: scalar table loads */
-        ql5 = qparams_uniform(B.qtab + qp5);
+        ql5 = qparams_uniform((const venc_qparams *)s_q); /* (uniform reads: the constants land in scalar registers) */
         if (threadIdx.x >= 448) { /* wave 7 has nothing to do in P5: this tile's share of the picture's SAD sum, one atomic per block */
             const int l7 = threadIdx.x - 448;
             uint32_t sad = 0;

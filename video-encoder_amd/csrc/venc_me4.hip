@@ -48,6 +48,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[8];
     __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
+    __shared__ int s_q[sizeof(venc_qparams) / sizeof(int)]; /* rate control: the picture's quantiser constants, fetched in P0 for P5 */
     __shared__ __attribute__((aligned(8))) uint32_t s_c8[T2_MBX * T2_MBY][2];
     uint2 *const s_h8 = (uint2 *)s_hv;
     static_assert(sizeof(uint2) * T2_WR * T2_HG == sizeof(uint4) * T4_VS * T2_HG, "h8 and the pair slots share one buffer");
@@ -128,6 +129,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         *(uint2 *)(s_cur + (tid >> 4) * T3_CW + (tid & 15) * 2) = cu;
         if (l32 == 0) s_prev[hw] = prev_early;
+        if (RC && tid < (int)(sizeof(venc_qparams) / sizeof(int))) {
+            /* (two dependent loads -- the picture's QP, then its row of the table -- issued here, beside the window's, instead of at the
+             * head of P5 where every block waited for them: the rate-control variant took 85 us alone where the fixed-QP one takes 74) */
+            const int qp0 = S.rc_history ? B.qp_cur[item] : S.qp_base;
+            s_q[tid] = ((const int *)(B.qtab + qp0))[tid];
+        }
     }
     __syncthreads();
     if (S.me_stop == 1) return;
@@ -410,8 +417,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     /* ---- P5: the tile's luma, decided from the LDS copies the search used (deferred form: venc_inter2.hip luma_block_defer) ---- */
     venc_qparams ql5 = g.ql;
     if (RC) {
-        const int qp5 = __builtin_amdgcn_readfirstlane(S.rc_history ? B.qp_cur[item] : S.qp_base);
-        ql5 = qparams_uniform(B.qtab + qp5);
+        ql5 = qparams_uniform((const venc_qparams *)s_q); /* (uniform reads: the constants land in scalar registers) */
         if (tidb >= 448) { /* wave 7: this tile's share of the picture's SAD sum, one atomic per block */
             const int l7 = (int)tidb - 448;
             uint32_t sad = 0;
