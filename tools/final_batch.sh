@@ -19,7 +19,6 @@ done
 cd $R
 for wl in 1080p 2160p; do python3 tools/pmc_summary.py $O/pmcf_$wl $O/pmcw_$wl $wl > /dev/null; done
 cp profiles/pmc_traffic.json $O/
-timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-240 $O/bench_default.json
 timeout -k 10 300 python bench.py --workload 2160p $Q > $O/bench_2160p.json 2> $O/bench_2160p.err; cut -c1-240 $O/bench_2160p.json
 timeout -k 10 300 python bench.py --serial-steps $Q > $O/bench_1080p_serial.json 2> $O/bench_1080p_serial.err
 # the optional coding tools (each checked bit-exact against the oracle on the first GOP), 1080p and for sub-sample refinement 2160p
@@ -46,6 +45,8 @@ done
 cd $R
 for wl in 1080p 2160p; do python3 tools/sq_summary.py $O/sq_$wl $wl profiles/sq_counters.json > $O/sq_counters_${wl}_isolated.txt 2> $O/sq_summary_$wl.err; done
 cp profiles/sq_counters.json $O/
+# the default line last in this half: it quotes the PMC traffic and the SQ counters collected above (same device sources)
+timeout -k 10 400 python bench.py > $O/bench_default.json 2> $O/bench_default.err; cut -c1-240 $O/bench_default.json
 fi
 if [[ $PART == *b* ]]; then
 timeout -k 10 300 python bench.py --steps 3 --warmup 2 --mode slices --workload 2160p $Q > $O/bench_slices1.json 2> $O/bench_slices1.err; cut -c1-240 $O/bench_slices1.json
