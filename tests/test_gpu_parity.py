@@ -307,6 +307,7 @@ def test_intra_three_kernels_equal_the_wavefront_kernel(venc, legacy_lib, w, h, 
 @pytest.mark.parametrize("env", [
     {"VENC_FUSE": "0"},                 # luma + chroma transform as k_inter_fused on the main chain (round 1's shape)
     {"VENC_FUSE": "1"},                 # every luma block coded inside the search kernels (round 2's shape; default: blocks with a level behind them)
+    {"VENC_GOP_HINT": "0"},             # a GOP's first P picture starts from the zero vector only (no hint from the previous unit)
     {"VENC_ME_BLOCKS": "3"},            # the search on three blocks per CU (k_me_pool) with the deferred transform
     {"VENC_ME_BLOCKS": "4"},            # ... on four (k_me_pool4), whatever the step size
     {"VENC_NZ_RPB": "4"},               # one follow-up block per search tile: many blocks, every share small

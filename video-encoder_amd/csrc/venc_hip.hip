@@ -879,6 +879,13 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     const int rs = (int)(c->step_no % VENC_RING), rs_prev = (int)((c->step_no + VENC_RING - 1) % VENC_RING);
     b.mvsad = c->b.mvsad + (size_t)rs * GN;
     b.mvsad_prev = c->b.mvsad + (size_t)rs_prev * GN;
+    /* The first P step of a GOP has no previous P picture: the I step left zeros in its slot, the zero vector is a poor start
+     * point for anything that moves, and every wave of the search took its second pass (124 us alone, 223 us beside the I
+     * pictures' entropy kernels, where a steady step takes 74 / 94).  Two slots back lies the last P step of the PREVIOUS unit
+     * (the ring is zeroed at open; the items there are the GOPs one unit earlier in the stream): its vectors are only a hint --
+     * start points steer the pruning, never the result -- but for a camera that keeps moving they are a good one. */
+    static const int gop_hint = getenv("VENC_GOP_HINT") ? atoi(getenv("VENC_GOP_HINT")) : 1;
+    if (gop_hint && !is_idr && !c->last_step_p && c->step_no >= 2) b.mvsad_prev = c->b.mvsad + (size_t)((c->step_no + VENC_RING - 2) % VENC_RING) * GN;
     if (g.subpel) b.mvq = c->b.mvq + (size_t)rs * GN;
     b.levels = c->b.levels + (size_t)rs * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs * GN;
