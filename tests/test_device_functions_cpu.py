@@ -236,3 +236,68 @@ def test_rate_control_rule_matches_the_oracle(hc, orc):
     assert L.orc_rc_qp(20, 1, 0, 0, 1) == 17 and L.orc_rc_qp(13, 1, 0, 0, 1) == 12 and L.orc_rc_qp(50, 0, 1, 65280, 1) == 51
     for qp in range(12, 52):
         assert hc.hc_make_qparams_matches(qp) == 1, qp
+
+
+# ---------------------------------------------------------------- round 3: venc_lines.h
+def test_deblock_line_filters_match_the_python_restatement(hc):
+    """k_deblock_ls's two line filters (csrc/venc_lines.h) against the second restatement of H.264 8.7.2.3 / 8.7.2.4 in
+    tests/test_oracle_deblock.py: the branching one for every strength 0 .. 4, the branch-free normal filter (the fast path of
+    P pictures) for strengths 0 .. 3 -- luma and chroma, a spread of QPs, random samples and smooth ones (so that the alpha / beta
+    tests pass often)."""
+    from test_oracle_deblock import ALPHA, BETA, TC0, _filter_line
+    hc.hc_dbk_line.argtypes = [C.c_void_p] + [C.c_int] * 5
+    hc.hc_dbk_line_normal.argtypes = [C.c_void_p] + [C.c_int] * 5
+    rng = np.random.default_rng(11)
+    checked = filtered = 0
+    for qp in (12, 20, 26, 30, 34, 40, 46, 51):
+        for chroma in (0, 1):
+            for bs in range(5):
+                for trial in range(400):
+                    if trial % 2:
+                        s = rng.integers(0, 256, 8)
+                    else:  # a step across the edge on a gentle slope: what the filter exists for
+                        base = int(rng.integers(8, 248))
+                        s = np.clip(base + rng.integers(-3, 4, 8) + np.array([0, 0, 0, 0, 1, 1, 1, 1]) * int(rng.integers(-12, 13)), 0, 255)
+                    want = _filter_line([int(v) for v in s], bs, qp, bool(chroma))
+                    tc0 = TC0[qp][bs - 1] if 1 <= bs <= 3 else 0
+                    a = np.array(s, dtype=np.int32)
+                    hc.hc_dbk_line(a.ctypes.data, bs, ALPHA[qp], BETA[qp], tc0, chroma)
+                    assert list(a) == want, (qp, chroma, bs, list(s))
+                    if bs < 4:
+                        b = np.array(s, dtype=np.int32)
+                        hc.hc_dbk_line_normal(b.ctypes.data, bs, ALPHA[qp], BETA[qp], tc0, chroma)
+                        assert list(b) == want, ("branch-free", qp, chroma, bs, list(s))
+                    checked += 1
+                    filtered += list(s) != want
+    assert filtered > checked // 20  # the filters did run
+
+
+def test_follow_up_blocks_find_every_listed_block(hc):
+    """k_me_fix's follow-up blocks see an item's listed 4x4 blocks as one concatenated list (csrc/venc_lines.h venc_nz_locate): every
+    entry k must map to its (tile, wave) segment and its place inside -- empty segments, full ones (64), clusters, ragged counts
+    per thread-segment (rpt = 4, 8, 32)."""
+    hc.hc_nz_locate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_void_p]
+    hc.hc_nz_locate.restype = C.c_int
+    rng = np.random.default_rng(5)
+    for rpt, regions in ((4, 1000), (8, 2040), (32, 8160), (8, 37)):
+        for kind in ("sparse", "clustered", "full", "empty"):
+            cnt = np.zeros(256 * rpt, dtype=np.uint32)
+            if kind == "sparse":
+                cnt[:regions] = rng.integers(0, 8, regions) * (rng.random(regions) < 0.4)
+            elif kind == "clustered":
+                lo = int(rng.integers(0, max(1, regions - 40)))
+                cnt[lo:lo + 40] = 64
+                cnt[:regions] = np.minimum(64, cnt[:regions] + (rng.random(regions) < 0.05) * rng.integers(1, 64, regions))
+            elif kind == "full":
+                cnt[:regions] = 64
+            per_thread = cnt.reshape(256, rpt).sum(axis=1)
+            part = np.concatenate([[0], np.cumsum(per_thread)]).astype(np.uint32)
+            cnt32 = (cnt.reshape(-1, 4) * np.array([1, 1 << 8, 1 << 16, 1 << 24], dtype=np.uint64)).sum(axis=1).astype(np.uint32)
+            total = int(part[256])
+            want = [(r, i) for r in range(256 * rpt) for i in range(int(cnt[r]))]
+            assert len(want) == total
+            idx = C.c_uint(0)
+            ks = range(total) if total <= 3000 else sorted(set([0, total - 1] + [int(v) for v in rng.integers(0, total, 3000)]))
+            for k in ks:
+                r = hc.hc_nz_locate(part.ctypes.data, cnt32.ctypes.data, rpt, k, C.byref(idx))
+                assert (r, idx.value) == want[k], (rpt, kind, k)

@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include "venc_device.h"
+#include "venc_lines.h"
 #include "venc_synth.h"
 
 extern "C" {
@@ -46,6 +47,13 @@ int hc_make_qparams_matches(int qp) {
     venc_make_qparams(qp, &b);
     return memcmp(&a, &b, sizeof(a)) == 0 && venc_chroma_qp(qp) == hc_chroma_qp(qp);
 }
+
+/* round 3: the in-loop filter's line functions and the follow-up's entry lookup (venc_lines.h) */
+void hc_dbk_line(int *s, int bs, int alpha, int beta, int tc0, int chroma) { venc_dbk_line(s, bs, alpha, beta, tc0, chroma != 0); }
+void hc_dbk_line_normal(int *s, int bs, int alpha, int beta, int tc0, int chroma) { /* s = p3 .. q3 as venc_dbk_line takes them */
+    venc_dbk_line_normal(chroma != 0, s[1], &s[2], &s[3], &s[4], &s[5], s[6], bs, alpha, beta, tc0);
+}
+int hc_nz_locate(const uint32_t *part, const uint32_t *cnt32, int rpt, uint32_t k, uint32_t *index) { return venc_nz_locate(part, cnt32, rpt, k, index); }
 
 void hc_fdct4(const int *x, int *w) { venc_fdct4(x, w); }
 void hc_idct4(const int *d, int *r) { venc_idct4(d, r); }

@@ -55,37 +55,8 @@ struct dbk_strip {
                                        the strip, 1 .. DBK_S the strip --, [1] the row above (entries 1 .. DBK_S) */
 };
 
-/* (A branch-free restatement with selects, the strong filter behind a wave-uniform test, was measured SLOWER: 376 -> 403 us per
- * launch, 6.5 M -> 8.3 M vector instructions -- most lines fail the alpha / beta test and the branches skip the rest.) */
-/* one line across an edge: s[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (chroma: p1 p0 q0 q1 in s[2..5]); 8.7.2.3 / 8.7.2.4 */
-DEVFN void dbk_line(int s[8], int bs, int alpha, int beta, int tc0, bool chroma) {
-    const int p3 = s[0], p2 = s[1], p1 = s[2], p0 = s[3], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
-    if (!(bs && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
-    const bool ap = !chroma && abs(p2 - p0) < beta, aq = !chroma && abs(q2 - q0) < beta;
-    if (bs < 4) {
-        const int tc = chroma ? tc0 + 1 : tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
-        const int delta = min(max((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc), tc);
-        s[3] = venc_clip_u8(p0 + delta);
-        s[4] = venc_clip_u8(q0 - delta);
-        const int avg = (p0 + q0 + 1) >> 1;
-        if (ap) s[2] = p1 + min(max((p2 + avg - (p1 << 1)) >> 1, -tc0), tc0);
-        if (aq) s[5] = q1 + min(max((q2 + avg - (q1 << 1)) >> 1, -tc0), tc0);
-    } else {
-        const bool small = !chroma && abs(p0 - q0) < ((alpha >> 2) + 2);
-        if (small && ap) {
-            s[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-            s[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
-            s[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-        } else
-            s[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-        if (small && aq) {
-            s[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-            s[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
-            s[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-        } else
-            s[4] = (2 * q1 + q0 + p1 + 2) >> 2;
-    }
-}
+/* the line filter: venc_lines.h (shared with k_deblock_ls and the host-check library) */
+#define dbk_line venc_dbk_line
 
 __global__ __launch_bounds__(64 * DBK_MAX_WAVES) void k_deblock(venc_geom g, venc_bufs B, venc_step S, int planes) {
     extern __shared__ __attribute__((aligned(16))) dbk_strip s_t[]; /* one tile per wave of the block (the launcher sizes it) */

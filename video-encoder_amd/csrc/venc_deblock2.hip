@@ -54,30 +54,6 @@ struct dl_fetch { /* what a helper lane holds for the macroblock three steps ahe
     uint2 ca;     /* ... chroma */
 };
 
-/* The normal filter (bS 1 .. 3, 8.7.2.3) of one line without a branch: p2 .. q2 in, p1 p0 q0 q1 out (unchanged where the line is not
- * filtered).  What a step of k_deblock_ls costs is the LENGTH of the filter wave's instruction stream, not the work of the lanes it
- * skips: dbk_line's nested tests (most lines fail the alpha / beta test) save a throughput-bound kernel a third of its
- * instructions and cost this one a branch each.  Same arithmetic as dbk_line, term by term. */
-template <bool CHROMA>
-DEVFN void dl_line_normal(int p2, int &p1, int &p0, int &q0, int &q1, int q2, int bs, int alpha, int beta, int tc0) {
-    const bool f = bs != 0 && (int)__builtin_amdgcn_sad_u8((uint32_t)p0, (uint32_t)q0, 0u) < alpha && (int)__builtin_amdgcn_sad_u8((uint32_t)p1, (uint32_t)p0, 0u) < beta &&
-                   (int)__builtin_amdgcn_sad_u8((uint32_t)q1, (uint32_t)q0, 0u) < beta;
-    const bool ap = !CHROMA && (int)__builtin_amdgcn_sad_u8((uint32_t)p2, (uint32_t)p0, 0u) < beta;
-    const bool aq = !CHROMA && (int)__builtin_amdgcn_sad_u8((uint32_t)q2, (uint32_t)q0, 0u) < beta;
-    const int tc = CHROMA ? tc0 + 1 : tc0 + (ap ? 1 : 0) + (aq ? 1 : 0);
-    const int delta = min(max((((q0 - p0) << 2) + (p1 - q1) + 4) >> 3, -tc), tc);
-    const int np0 = venc_clip_u8(p0 + delta), nq0 = venc_clip_u8(q0 - delta);
-    if (!CHROMA) {
-        const int avg = (p0 + q0 + 1) >> 1;
-        const int np1 = p1 + min(max((p2 + avg - (p1 << 1)) >> 1, -tc0), tc0);
-        const int nq1 = q1 + min(max((q2 + avg - (q1 << 1)) >> 1, -tc0), tc0);
-        p1 = f && ap ? np1 : p1;
-        q1 = f && aq ? nq1 : q1;
-    }
-    p0 = f ? np0 : p0;
-    q0 = f ? nq0 : q0;
-}
-
 /* one phase of one macroblock (PH 0-3: vertical edges, 4-7: horizontal edges); it runs if one of the wave's four macroblocks has a
  * strength on it.  s / sl: the slots of the macroblock and of its left neighbour; bs4: the four segment strengths of the phase */
 template <bool CHROMA, int PH>
@@ -102,13 +78,13 @@ DEVFN void dl_phase(dl_row &T, int s, int sl, int k, bool act, uint32_t bs4, uin
                 uint32_t *p = ep ? q - 1 : cl + (4 + kk) * rd + rd - 1;
                 const uint32_t w0 = *p, w1 = *q;
                 int p1 = (int)((w0 >> 16) & 255u), p0 = (int)(w0 >> 24), q0 = (int)(w1 & 255u), q1 = (int)((w1 >> 8) & 255u);
-                dl_line_normal<CHROMA>((int)((w0 >> 8) & 255u), p1, p0, q0, q1, (int)((w1 >> 16) & 255u), lbs, alpha, beta, tc0);
+                venc_dbk_line_normal(CHROMA, (int)((w0 >> 8) & 255u), &p1, &p0, &q0, &q1, (int)((w1 >> 16) & 255u), lbs, alpha, beta, tc0);
                 *p = (w0 & 0xffffu) | ((uint32_t)p1 << 16) | ((uint32_t)p0 << 24);
                 *q = (w1 & 0xffff0000u) | (uint32_t)q0 | ((uint32_t)q1 << 8);
             } else {
                 uint8_t *col = (uint8_t *)cs + (4 * ep) * (4 * rd) + kk;
                 int p2 = CHROMA ? 0 : col[1 * 4 * rd], p1 = col[2 * 4 * rd], p0 = col[3 * 4 * rd], q0 = col[4 * 4 * rd], q1 = col[5 * 4 * rd], q2 = CHROMA ? 0 : col[6 * 4 * rd];
-                dl_line_normal<CHROMA>(p2, p1, p0, q0, q1, q2, lbs, alpha, beta, tc0);
+                venc_dbk_line_normal(CHROMA, p2, &p1, &p0, &q0, &q1, q2, lbs, alpha, beta, tc0);
                 if (!CHROMA) col[2 * 4 * rd] = (uint8_t)p1;
                 col[3 * 4 * rd] = (uint8_t)p0;
                 col[4 * 4 * rd] = (uint8_t)q0;

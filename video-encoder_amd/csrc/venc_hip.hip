@@ -19,6 +19,7 @@
 #include <time.h>
 
 #include "../../include/venc_hip.h"
+#include "venc_lines.h"
 #include "venc_kernels.hip"
 static_assert(offsetof(venc_mbinfo, cbp) % 4 == 0 && sizeof(venc_mbinfo) == 32, "luma_block_redo ORs a macroblock's luma cbp bits into the aligned word that starts at cbp");
 #include "venc_inter2.hip"

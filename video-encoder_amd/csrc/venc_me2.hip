@@ -112,27 +112,8 @@ DEVFN void luma_nz_redo(const venc_geom &g, const venc_bufs &B, const venc_step 
     const uint32_t chunk = (total + (uint32_t)nz_blocks - 1u) / (uint32_t)nz_blocks;
     const uint32_t lo = (uint32_t)nzblock * chunk, hi = min(total, lo + chunk);
     for (uint32_t k = lo + (uint32_t)tid; k < hi; k += 64 * FIX_WAVES) {
-        int t = 0; /* the last thread-segment that starts at or before entry k (it is not empty: the next one starts behind k) */
-#pragma unroll
-        for (int step = 128; step; step >>= 1)
-            if (s_part[t + step] <= k) t += step;
-        uint32_t rem = k - s_part[t];
-        int r = t * rpt;
-        for (int q = 0; q < rpt4; q++) { /* walk the segment's counts: rem < their sum */
-            const uint32_t wd = s_cnt32[t * rpt4 + q];
-            const uint32_t c0 = wd & 255u, c1 = (wd >> 8) & 255u, c2 = (wd >> 16) & 255u, c3 = wd >> 24;
-            if (rem < c0 + c1 + c2 + c3) {
-                if (rem >= c0) {
-                    rem -= c0, r++;
-                    if (rem >= c1) {
-                        rem -= c1, r++;
-                        if (rem >= c2) rem -= c2, r++;
-                    }
-                }
-                break;
-            }
-            rem -= c0 + c1 + c2 + c3, r += 4;
-        }
+        uint32_t rem;
+        const int r = venc_nz_locate(s_part, s_cnt32, rpt, k, &rem); /* (venc_lines.h; tests/test_device_functions_cpu.py) */
         const size_t slot = (ibase + r) * 64 + rem;
         const uint32_t e = B.nz_ids[slot];
         const uint4 cur4 = B.nz_rows[2 * slot], pred4 = B.nz_rows[2 * slot + 1];
