@@ -222,7 +222,8 @@ static void fill_qparams(venc_qparams *q, int qp) {
 }
 
 static int entropy_flush(venc_ctx *c);
-/* the in-loop filter of a step's pictures (venc_deblock.hip): one block per (slice, item), a wave per macroblock row */
+/* the in-loop filter of a step's pictures: one block per (slice, item) -- k_deblock_ls (venc_deblock2.hip): the slice's rows in lock-step,
+ * four rows per filter wave + as many helper waves; VENC_DBK=strip: k_deblock (venc_deblock.hip), a wave per macroblock row */
 static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, const venc_bufs &b, const venc_step &S, int n_items, int planes) {
     int max_rows = 1;
     for (int s = S.slice0; s < S.slice1; s++) max_rows = c->slice_rows[s + 1] - c->slice_rows[s] > max_rows ? c->slice_rows[s + 1] - c->slice_rows[s] : max_rows;

@@ -1,5 +1,7 @@
 /*
- * venc_me3.hip -- k_me_pool: the shipped motion search.
+ * venc_me3.hip -- k_me_pool: the motion search on three blocks per CU.  Since round 3 the shipped
+ * search is k_me_pool4 (venc_me4.hip: the same search laid out for four blocks per CU); this kernel stays behind VENC_ME_BLOCKS=3 as
+ * its A/B partner and as the carrier of round 2's inline transform (VENC_FUSE=1), and venc_me4.hip uses its helpers.
  *
  * Same search as k_me_tile (venc_me2.hip): exact +-16 full search of every 16x16 macroblock by
  * successive elimination on 8x8 block sums built inside the kernel; the result is the argmin of
