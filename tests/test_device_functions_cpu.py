@@ -301,3 +301,31 @@ def test_follow_up_blocks_find_every_listed_block(hc):
             for k in ks:
                 r = hc.hc_nz_locate(part.ctypes.data, cnt32.ctypes.data, rpt, k, C.byref(idx))
                 assert (r, idx.value) == want[k], (rpt, kind, k)
+
+
+# ---------------------------------------------------------------- round 4: the P pictures' entries (venc_cavlc_p.hip)
+def test_register_head_bit_sink_equals_the_plain_sink(hc):
+    """venc_bitsink4 (four words in registers, the rest spilled at their word index; what a lane of k_cavlc_p2 codes an entry
+    into) against venc_bitsink, word for word: a prefix of 0 .. 32 bits that moves every later code across the word boundaries,
+    two Exp-Golomb codes and one residual block of any density, up to strings beyond 128 bits."""
+    hc.hc_cavlc_block_mem4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(4)
+    words = np.zeros(64, np.uint32)
+    spilled = 0
+    for max_coef, first in ((16, 0), (15, 1), (4, 0)):
+        for nC in ((-1,) if max_coef == 4 else (0, 2, 4, 8)):
+            for density in (0.0, 0.2, 0.7, 1.0):
+                for big in (False, True):
+                    for plen in (0, 1, 7, 31, 32):
+                        blk = _rand_block(rng, max_coef, density, big)
+                        c = np.zeros(16, np.int16)
+                        c[first:first + max_coef] = blk[:max_coef]
+                        words[:] = 0
+                        pcode = int(rng.integers(0, 1 << plen)) if plen else 0
+                        bits = hc.hc_cavlc_block_mem4(c.ctypes.data, first, max_coef, nC, pcode, plen, words.ctypes.data)
+                        assert bits > 0, (bits, max_coef, nC, blk)
+                        nw = (bits + 31) // 32
+                        assert np.array_equal(words[:nw], words[32:32 + nw]), (max_coef, nC, plen, blk)
+                        assert not words[nw:32].any()  # nothing beyond the string (the pack kernel ORs whole words)
+                        spilled += nw > 4
+    assert spilled > 20

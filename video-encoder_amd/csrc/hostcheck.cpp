@@ -103,6 +103,39 @@ int hc_cavlc_block_mem(const short *c16, int first, int max_coef, int nC, unsign
     for (int i = 0; i < nb; i++) out[i] = (unsigned char)(words[i >> 2] >> (24 - 8 * (i & 3)));
     return bits;
 }
+/* round 4: the sink with four words in registers (venc_bitsink4, the P pictures' entries) must produce the bits of the plain sink:
+ * words[0..3] = its head registers, words[4..] = what it spilled; returns the bit count, or -1 - plain count on a mismatch of counts */
+int hc_cavlc_block_mem4(const short *c16, int first, int max_coef, int nC, unsigned prefix_code, int prefix_len, unsigned *words) {
+    static uint16_t tab[VENC_TAB_SIZE];
+    memcpy(tab + VENC_TAB_TOKEN, venc_vlc_coeff_token, 272 * 2);
+    memcpy(tab + VENC_TAB_TOKEN_CDC, venc_vlc_coeff_token_cdc, 20 * 2);
+    memcpy(tab + VENC_TAB_TZ, venc_vlc_total_zeros, 240 * 2);
+    memcpy(tab + VENC_TAB_TZ_CDC, venc_vlc_total_zeros_cdc, 12 * 2);
+    memcpy(tab + VENC_TAB_RUN, venc_vlc_run_before, 112 * 2);
+    uint32_t spill[32];
+    memset(spill, 0, sizeof(spill));
+    venc_bitsink4 b;
+    venc_bs4_init(&b, spill);
+    if (prefix_len) venc_bs_put(&b, prefix_code, prefix_len);
+    venc_bs_ue(&b, 5u);
+    venc_bs_se(&b, -3);
+    venc_cavlc_block_mem(&b, c16, venc_nzmask_mem(c16, first, max_coef), first, max_coef, nC, tab);
+    const int bits = venc_bs_flush(&b);
+    uint32_t ref[32];
+    memset(ref, 0, sizeof(ref));
+    venc_bitsink r;
+    venc_bs_init(&r, ref);
+    if (prefix_len) venc_bs_put(&r, prefix_code, prefix_len);
+    venc_bs_ue(&r, 5u);
+    venc_bs_se(&r, -3);
+    venc_cavlc_block_mem(&r, c16, venc_nzmask_mem(c16, first, max_coef), first, max_coef, nC, tab);
+    const int rbits = venc_bs_flush(&r);
+    if (bits != rbits) return -1 - rbits;
+    words[0] = b.h0, words[1] = b.h1, words[2] = b.h2, words[3] = b.h3;
+    for (int i = 4; i < 32; i++) words[i] = spill[i];
+    for (int i = 0; i < 32; i++) words[32 + i] = ref[i];
+    return bits;
+}
 int hc_ue_bits(unsigned v, unsigned char *out) {
     uint32_t words[4];
     venc_bitsink b;

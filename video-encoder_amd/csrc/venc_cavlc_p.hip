@@ -1,111 +1,184 @@
 /*
- * venc_cavlc_p.hip -- entropy coding of P pictures, ONE LANE PER SYNTAX UNIT of a macroblock
- * (SURVEY.md section 8a row a4.4).
+ * venc_cavlc_p.hip -- entropy coding of P pictures, ONE LANE PER SYNTAX ENTRY.
  *
- * A macroblock of a P picture is cut into seven units that can be coded independently, because every CAVLC
- * context (nC) comes from the TotalCoeff values the transform kernels already stored, not from coded bits:
- *   unit 0  slice header (first macroblock of a slice), mb_skip_run .. mb_qp_delta, luma 8x8 block 0
- *   unit 1-3  luma 8x8 blocks 1-3 (four 4x4 blocks each)        unit 4  Cb and Cr DC
- *   unit 5  Cb AC (four blocks)                                 unit 6  Cr AC
- * Each unit appends to its own 64-word bit string in the macroblock's region of mbbits; k_scan turns the seven
- * lengths into offsets and k_pack gathers the strings.
- * The first version gave a whole macroblock to one lane: a wave then took as long as the heaviest of its 64
- * macroblocks -- up to 26 block codings, each behind a dependent load of its levels, ~100 us -- and the entropy
- * chain became the longer of the two chains of a step.  A unit is at most four blocks.
- * The second gave every macroblock eight lanes: 45 us, but seven of eight lanes had nothing to code (a P macroblock
- * of the 1080p clip averages 17-40 bits), and those 10 000 mostly idle waves held 80 % of the chip's wave slots
- * beside the motion search of the next step.  Now k_skip lists the units that exist (header units of coded
- * macroblocks, residual units with a coded_block_pattern bit) and k_cavlc_p gives one lane to each list entry.
- * I pictures (26 dense blocks in every macroblock) stay on k_cavlc (one lane per block, LDS concatenation).
+ * An ENTRY is the smallest piece of a P macroblock's syntax that can be coded on its own, because every CAVLC context (nC)
+ * comes from the TotalCoeff values the transform kernels already stored, not from coded bits:
+ *   slot 0        the macroblock header: slice header (first macroblock of a slice), mb_skip_run, mb_type, mvd_l0,
+ *                 coded_block_pattern, mb_qp_delta -- or, for a skipped macroblock that ends its slice, the last mb_skip_run
+ *   slot 1 .. 16  luma 4x4 block luma4x4BlkIdx = slot - 1 (present iff its 8x8 block's coded_block_pattern bit is set)
+ *   slot 17, 18   Cb, Cr DC                 slot 19 .. 26  Cb, Cr AC blocks
+ * Slots are numbered in bitstream order, so the entries of a slice sorted by (macroblock, slot) ARE its slice_data().
+ *
+ * History.  Round 1 gave a macroblock to one lane (a wave lasted as long as its heaviest macroblock, ~100 us), then eight
+ * lanes (seven idle).  Rounds 2-3 cut a macroblock into seven UNITS (header + luma 8x8 block 0, three more 8x8 blocks, chroma
+ * DC, Cb AC, Cr AC), listed the non-empty ones with one atomic per block and gave a lane to each: 77 us per batch of four
+ * steps at 28 % vector utilisation -- five of six listed units are headers, the sixth carries up to four residual blocks and
+ * every wave held one of those; each unit wrote a word here and there into its own 256-byte string of a 2 KB region per
+ * macroblock, k_scan turned eight unit lengths per macroblock into offsets and k_pack read ONE 128-BYTE LINE PER UNIT to collect
+ * a few words: 98 MB read to write 1.5 MB (profiles/pmc_traffic.json of round 3).
+ *
+ * Round 4 (this file):
+ *   k_skip2     one lane per macroblock, blocks of 256 macroblocks OF ONE SLICE ("segments"): P_Skip decision, the mask of
+ *               coded macroblocks (slice-relative words), and the segment's entries in bitstream order -- a block scan, no atomic
+ *   k_cavlc_p2  one lane per entry of a segment: the entry's bit string leaves as ONE 16-byte store (venc_bitsink4: four words
+ *               in registers; the rare entry beyond 128 bits spills into the macroblock's region of mbbits), its bit offset
+ *               inside the segment comes from a block scan of the lengths, the segment's total goes to seg_bits
+ *   k_pack_p    one block per segment: every block sums the picture's segment totals itself (a few dozen numbers: no scan kernel),
+ *               ORs its entries into an LDS window at their bit offsets and streams the window out; the block of a picture's
+ *               first segment also writes the slice table
+ * A lane's work is one header or ONE 4x4 block (most of them a coeff_token and a level or two), the gather reads 20 bytes per
+ * entry from dense arrays, and k_scan has left the P chain.  I pictures (26 dense blocks in every macroblock) stay on k_cavlc /
+ * k_scan / k_pack (venc_kernels.hip).
  */
 
+#define ENT_SEG_MBS 256   /* macroblocks of one slice per segment */
+#define ENT_PER_MB 27     /* entries a macroblock can have */
+#define ENT_THREADS 256
 
-/* ================================================================== k_skip
- * P_Skip decisions of a P picture (7.3.4), one lane per macroblock: no residual and the vector a decoder infers
- * (mb_is_p_skip).  The result is a bit mask of CODED macroblocks, one 64-bit word per 64 macroblocks of the picture
- * (wave ballot); k_cavlc_p derives mb_skip_run from it by looking backwards for the previous coded macroblock of the
- * slice -- a count-leading-zeros per word, and whole rows of skipped macroblocks are a handful of words.
- * The same lane lists the macroblock's non-empty syntax units (mb << 3 | unit) for k_cavlc_p -- a wave scan and one
- * atomic per wave; the order of the list is irrelevant, every unit writes to its own place -- and zeroes the
- * macroblock's eight unit lengths, which the coded units then overwrite. */
-__global__ __launch_bounds__(256) void k_skip(venc_geom g, venc_bufs B, venc_step S) {
-    const int item = blockIdx.z, tid = threadIdx.x;
-    const int base = (S.mb0 & ~63) + blockIdx.x * 256; /* words are aligned to multiples of 64 macroblocks of the picture */
-    const int mb = base + tid;
-    const bool in = mb >= S.mb0 && mb < S.mb1;
-    const int mbc = in ? mb : S.mb0;
-    const int mx = mbc % g.mbw, my = mbc / g.mbw;
-    const int srow = slice_first_row_of(g, my);
-    const venc_mbinfo *infos = B.mbinfo + (size_t)item * g.nmb;
-    const uint32_t rec = ((const uint32_t *)(infos + mbc))[6]; /* bytes 24..27: cbp, flags, cbpc, pad */
-    const int cbp = (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4);
-    const bool skip = in && mb_is_p_skip(g, B.mvsad + (size_t)item * g.nmb, mbc, mx, mx > 0, my > srow, cbp);
+/* segment index of (pair v, slice s, segment j of the slice) and the geometry that goes with it */
+DEVFN size_t ent_seg(const venc_geom &g, const venc_bufs &B, int v, int s, int j) { return ((size_t)v * g.n_slices + s) * B.ent_spp + j; }
+
+/* ================================================================== k_skip2
+ * grid = (segments per slice, slices of the band, (step, item) pairs).  P_Skip (7.3.4): no residual and the vector a decoder
+ * infers (mb_is_p_skip).  The coded-macroblock mask is a wave ballot per 64 macroblocks OF THE SLICE; k_cavlc_p2 derives
+ * mb_skip_run from it by looking backwards for the previous coded macroblock -- a count-leading-zeros per word, and whole rows of
+ * skipped macroblocks are a handful of words.
+ * The segment's entries are listed twice: in bitstream order (ent_list[rank] = mb << 5 | slot: what rank means downstream) and
+ * SORTED BY KIND for the coder (ent_cls: headers | blocks with a level | blocks without; element = rank << 13 | macroblock of the
+ * segment << 5 | slot), so that a wave of k_cavlc_p2 holds one kind of work.  Unsorted (first form of this round) a wave walked the
+ * header path AND the longest block of its 64 entries for what was mostly one-bit tokens of empty blocks: 14.0 M vector
+ * instructions per batch of four 1080p steps, half a motion search. */
+DEVFN uint32_t nonzero_bytes4(uint32_t w) { /* bit k = byte k of w is not zero */
+    return (uint32_t)((w & 0xffu) != 0u) | ((uint32_t)((w & 0xff00u) != 0u) << 1) | ((uint32_t)((w & 0xff0000u) != 0u) << 2) | ((uint32_t)((w >> 24) != 0u) << 3);
+}
+__global__ __launch_bounds__(ENT_SEG_MBS) void k_skip2(venc_geom g, venc_bufs B, venc_step S) {
+    __shared__ uint32_t s_wa[ENT_SEG_MBS / 64], s_wh[ENT_SEG_MBS / 64];
+    const int v = blockIdx.z, s = S.slice0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+    const int srow = B.slice_first_row[s];
+    const int first = srow * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
+    if (j * ENT_SEG_MBS >= last - first) return;
+    const int rel = j * ENT_SEG_MBS + tid, mb = first + rel;
+    const bool in = mb < last;
+    const int mbc = in ? mb : first;
+    const int my = mbc / g.mbw, mx = mbc - my * g.mbw;
+    const uint4 *ip = (const uint4 *)(B.mbinfo + (size_t)v * g.nmb + mbc); /* the whole record: nnz[24], cbp, flags, cbpc */
+    const uint4 o0 = ip[0], o1 = ip[1];
+    const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u);
+    const bool skip = in && mb_is_p_skip(g, B.mvsad + (size_t)v * g.nmb, mbc, mx, mx > 0, my > srow, cbpl | (cbpc << 4));
     const unsigned long long coded = __ballot(in && !skip);
-    if ((tid & 63) == 0 && (mb >> 6) < (g.nmb + 63) / 64) B.codedmask[(size_t)item * ((g.nmb + 63) / 64) + (mb >> 6)] = coded;
-    /* units: 0 header (+ luma 8x8 block 0), 1-3 luma 8x8 blocks, 4 chroma DC, 5/6 Cb/Cr AC; a slice that ends in
-     * skipped macroblocks codes their count in unit 0 of its last macroblock */
-    uint32_t um = 0;
+    if ((tid & 63) == 0) B.codedmask[((size_t)v * g.n_slices + s) * B.ent_wps + (rel >> 6)] = coded;
+    uint32_t em = 0, nm = 0; /* bit = slot: entries; those that are blocks with a level (the chroma DC blocks count as such: their record has no count) */
     if (in) {
-        const int cbpl = cbp & 15, cbpc = cbp >> 4;
-        const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
-        /* unit 0 of a skipped macroblock still exists when it carries the slice header or the slice's last mb_skip_run */
-        um = skip ? ((mb == slice_last || (mx == 0 && my == srow)) ? 1u : 0u) : 1u | (uint32_t)(cbpl & 14) | (cbpc > 0 ? 16u : 0u) | (cbpc == 2 ? 96u : 0u);
-        *(uint4 *)(B.ubits + ((size_t)item * g.nmb + mb) * 8) = make_uint4(0u, 0u, 0u, 0u);
+        if (skip)
+            em = (mb == last - 1 || rel == 0) ? 1u : 0u; /* the slice's last mb_skip_run / its header */
+        else {
+            em = 1u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) em |= ((cbpl >> q) & 1) ? 0xfu << (1 + 4 * q) : 0u;
+            em |= cbpc > 0 ? 3u << 17 : 0u;
+            em |= cbpc == 2 ? 0xffu << 19 : 0u;
+            const uint32_t nzr = nonzero_bytes4(o0.x) | (nonzero_bytes4(o0.y) << 4) | (nonzero_bytes4(o0.z) << 8) | (nonzero_bytes4(o0.w) << 12); /* luma, raster order */
+#pragma unroll
+            for (int bk = 0; bk < 16; bk++) nm |= ((nzr >> (blk_y(bk) * 4 + blk_x(bk))) & 1u) << (1 + bk);
+            nm |= 3u << 17;
+            nm |= (nonzero_bytes4(o1.x) | (nonzero_bytes4(o1.y) << 4)) << 19;
+            nm &= em;
+        }
     }
-    /* one atomic per block (the items' counters sit 128 bytes apart: atomics on one cache line serialise at ~11 ns each,
-     * which made this kernel 58 us at 2160p when every wave pulled and the ten counters shared a line) */
-    __shared__ uint32_t s_wtot[4], s_base;
-    const uint32_t n = (uint32_t)__popc(um), incl = wave_scan_incl(n);
-    if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+    const uint32_t n_all = (uint32_t)__popc(em), n_n = (uint32_t)__popc(nm), n_h = em & 1u;
+    const uint32_t ia = wave_scan_incl(n_all | (n_n << 16)), ih = wave_scan_incl(n_h);
+    if ((tid & 63) == 63) s_wa[tid >> 6] = ia, s_wh[tid >> 6] = ih;
     __syncthreads();
-    if (tid == 0) {
-        const uint32_t total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
-        s_base = total ? atomicAdd(&B.unit_count[item * VENC_COUNTER_STRIDE], total) : 0u;
+    uint32_t xa = ia - (n_all | (n_n << 16)), xh = ih - n_h, ta = 0, th = 0;
+#pragma unroll
+    for (int k = 0; k < ENT_SEG_MBS / 64; k++) {
+        const uint32_t a = s_wa[k], h = s_wh[k];
+        xa += k < (tid >> 6) ? a : 0u;
+        xh += k < (tid >> 6) ? h : 0u;
+        ta += a;
+        th += h;
     }
-    __syncthreads();
-    uint32_t at = s_base + incl - n;
-    for (int k = 0; k < (tid >> 6); k++) at += s_wtot[k];
-    uint32_t *list = B.unit_list + (size_t)item * g.nmb * 7;
-    while (um) {
-        const int u = __builtin_ctz(um);
-        um &= um - 1u;
-        list[at++] = ((uint32_t)mb << 3) | (uint32_t)u;
+    const uint32_t total = ta & 0xffffu, tot_n = ta >> 16;
+    uint32_t rank = xa & 0xffffu, pos_n = th + (xa >> 16), pos_h = xh, pos_e = th + tot_n + (rank - xh - (xa >> 16));
+    const size_t seg = ent_seg(g, B, v, s, j);
+    uint32_t *list = B.ent_list + seg * B.ent_cap, *cls = B.ent_cls + seg * B.ent_cap;
+    while (em) {
+        const int slot = __builtin_ctz(em);
+        em &= em - 1u;
+        const uint32_t rec = (rank << 13) | ((uint32_t)tid << 5) | (uint32_t)slot;
+        list[rank++] = ((uint32_t)mb << 5) | (uint32_t)slot;
+        if (slot == 0)
+            cls[pos_h++] = rec;
+        else if ((nm >> slot) & 1u)
+            cls[pos_n++] = rec;
+        else
+            cls[pos_e++] = rec;
     }
+    if (tid == 0) *(uint4 *)(B.ent_count + 4 * seg) = make_uint4(total, th, tot_n, 0u);
 }
 
-/* P_Skip macroblocks directly before macroblock mb in its slice (first macroblock: `first`), from the coded-macroblock mask */
-DEVFN uint32_t skip_run_before(const unsigned long long *mask, int mb, int first) {
-    int w = mb >> 6;
-    unsigned long long m = mask[w] & ((1ull << (mb & 63)) - 1ull); /* coded macroblocks below mb in its word */
+/* P_Skip macroblocks directly before the macroblock at slice-relative index rel, from the slice's coded-macroblock mask */
+DEVFN uint32_t skip_run_before(const unsigned long long *mask, int rel) {
+    int w = rel >> 6;
+    unsigned long long m = mask[w] & ((1ull << (rel & 63)) - 1ull); /* coded macroblocks below rel in its word */
     for (;;) {
-        if ((w << 6) < first) m &= ~((1ull << (first & 63)) - 1ull); /* (only the slice's first word can start before it) */
-        if (m) return (uint32_t)(mb - 1 - ((w << 6) + 63 - __builtin_clzll(m)));
-        if ((w << 6) <= first) return (uint32_t)(mb - first);
+        if (m) return (uint32_t)(rel - 1 - ((w << 6) + 63 - __builtin_clzll(m)));
+        if (w == 0) return (uint32_t)rel;
         w--;
         m = mask[w];
     }
 }
 
-/* Blocks of 1024 lanes (pictures up to ~2.5K x 10 items; 512 beyond, where the listed units need the whole chip
- * anyway): the listed units of a picture then occupy a hundred CUs instead of landing, a few waves each, on all
- * 256 -- any resident block of this kernel (62 VGPRs, LDS) costs the motion search of the next step, which runs
- * beside it, its third block on that CU.  1080p: k_me_pool beside the entropy chain 87 -> 78 us with 1024 lanes per
- * block, 85 us with 512; 2160p: no difference for the search, but 1024-lane blocks wait for CUs with room for their
- * 38 KB (k_cavlc_p 107 -> 245 us beside the search).  The per-lane strips are dynamic LDS: 36 bytes per lane. */
-#define CAVLC_P_MAX_THREADS 1024
-#define CAVLC_P_BLOCK_LANES (40 * 1024) /* lanes per item: blocks loop over longer lists */
-__global__ __launch_bounds__(CAVLC_P_MAX_THREADS) void k_cavlc_p(venc_geom g, venc_bufs B, venc_step S) {
-    extern __shared__ uint32_t s_lv[]; /* per lane: the 16 levels of the block being coded (+1 dword against bank conflicts) */
-    const uint32_t nthreads = blockDim.x;
+/* a residual block's place in the records: level slot, scan range, the counts of its left / upper neighbours -> nC (9.2.1) */
+DEVFN int ent_block_nc(const venc_geom &g, const venc_mbinfo *infos, int mb, int lslot, bool aL, bool aT, int &firstc, int &maxc) {
+    firstc = 0, maxc = 16;
+    if (lslot == 17 || lslot == 18) {
+        maxc = 4;
+        return -1;
+    }
+    int ia, ib;
+    bool inA, inB;
+    if (lslot < 16) {
+        const int bx = blk_x(lslot), by = blk_y(lslot);
+        inA = bx > 0, inB = by > 0;
+        ia = inA ? by * 4 + bx - 1 : by * 4 + 3;
+        ib = inB ? (by - 1) * 4 + bx : 12 + bx;
+    } else {
+        firstc = 1, maxc = 15;
+        const int kk = (lslot - 19) & 3, nb = 16 + 4 * ((lslot - 19) >> 2);
+        const int bx = kk & 1, by = kk >> 1;
+        inA = bx > 0, inB = by > 0;
+        ia = inA ? nb + 2 * by : nb + 2 * by + 1;
+        ib = inB ? nb + bx : nb + 2 + bx;
+    }
+    const bool haveA = inA || aL, haveB = inB || aT;
+    const int nA = haveA ? (int)infos[inA ? mb : mb - 1].nnz[ia] : 0;
+    const int nB = haveB ? (int)infos[inB ? mb : mb - g.mbw].nnz[ib] : 0;
+    return venc_nc(haveA, nA, haveB, nB);
+}
+
+/* ================================================================== k_cavlc_p2
+ * grid as k_skip2; the waves of a block walk the segment's headers, then its blocks with a level, then its empty blocks (no
+ * barrier between them), leave every entry's string at head[rank] and its length in LDS, and the block ends with an exclusive scan
+ * of the lengths in rank order.  Dynamic LDS: 36 bytes per lane (the 16 levels of the block being coded + a dword against bank
+ * conflicts), then 2 bytes per entry the segment can hold. */
+__global__ __launch_bounds__(ENT_THREADS) void k_cavlc_p2(venc_geom g, venc_bufs B, venc_step S) {
+    extern __shared__ uint32_t s_dyn[];
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
-    const int item = blockIdx.z, tid = threadIdx.x;
-    /* the other set of unit counters: read last by the previous P batch's k_cavlc_p, filled next by the next one's k_skip
-     * (which may cover more (step, item) pairs than this launch: all of them are cleared) */
-    if (blockIdx.x == 0 && item == 0 && tid < B.vcap) B.unit_count_next[tid * VENC_COUNTER_STRIDE] = 0;
-    const uint32_t count = B.unit_count[item * VENC_COUNTER_STRIDE];
-    const uint32_t *list = B.unit_list + (size_t)item * g.nmb * 7;
-    if (blockIdx.x * nthreads >= count) return; /* whole block: nothing listed for it */
-    for (int i = tid; i < VENC_TAB_SIZE; i += (int)nthreads) {
+    __shared__ uint32_t s_wtot[2][ENT_THREADS / 64];
+    const int v = blockIdx.z, s = S.slice0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+    const int srow = B.slice_first_row[s];
+    const int first = srow * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
+    if (j * ENT_SEG_MBS >= last - first) return;
+    const size_t seg = ent_seg(g, B, v, s, j);
+    const uint4 cc = *(const uint4 *)(B.ent_count + 4 * seg);
+    const uint32_t count = min(cc.x, B.ent_cap), n_h = min(cc.y, count), n_hn = min(cc.y + cc.z, count);
+    const uint32_t *cls = B.ent_cls + seg * B.ent_cap;
+    uint4 *head = B.ent_head + seg * B.ent_cap;
+    uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
+    lds_u32 *strip = (lds_u32 *)(s_dyn + tid * 9); /* (written as dwords, read by the coder as int16: may_alias, see venc_kernels.hip) */
+    uint16_t *s_len = (uint16_t *)(s_dyn + ENT_THREADS * 9);
+    for (int i = tid; i < VENC_TAB_SIZE; i += ENT_THREADS) {
         s_tab[i] = i < VENC_TAB_TOKEN_CDC  ? venc_vlc_coeff_token[i]
                  : i < VENC_TAB_TZ         ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
                  : i < VENC_TAB_TZ_CDC     ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
@@ -113,105 +186,220 @@ __global__ __launch_bounds__(CAVLC_P_MAX_THREADS) void k_cavlc_p(venc_geom g, ve
                                            : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
     __syncthreads();
-  for (uint32_t base_e = blockIdx.x * nthreads; base_e < count; base_e += gridDim.x * nthreads) {
-    const bool valid = base_e + tid < count;
-    const uint32_t entry = list[valid ? base_e + tid : base_e];
-    const int unit = (int)(entry & 7u);
-    const int mb = (int)(entry >> 3);
-    const int mx = mb % g.mbw, my = mb / g.mbw;
-    const int srow = slice_first_row_of(g, my);
-    const bool aL = mx > 0, aT = my > srow;
-    const venc_mbinfo *infos = B.mbinfo + (size_t)item * g.nmb;
-    const uint4 *ip = (const uint4 *)(infos + mb);
-    const uint4 *lp = (const uint4 *)(infos + (aL ? mb - 1 : mb));
-    const uint4 *tp = (const uint4 *)(infos + (aT ? mb - g.mbw : mb));
-    const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
-    if (!valid) continue;
-
-    const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
-    uint32_t *strip = s_lv + tid * 9;
-    const int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
-    uint16_t *ubits = B.ubits + ((size_t)item * g.nmb + mb) * 8;
-    const unsigned long long *mask = B.codedmask + (size_t)item * ((g.nmb + 63) / 64);
-    const bool skipped = !((mask[mb >> 6] >> (mb & 63)) & 1ull); /* k_skip */
-    venc_bitsink bs;
-    venc_bs_init(&bs, B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS + unit * VENC_UNIT_WORDS);
-
-    /* blocks of this unit: slots first_slot .. first_slot + n_slots - 1 of the level record */
-    int first_slot = 0, n_slots = 0;
-    if (unit < 4) {
-        first_slot = 4 * unit;
-        n_slots = (!skipped && ((cbpl >> unit) & 1)) ? 4 : 0;
-    } else if (unit == 4) {
-        first_slot = 17;
-        n_slots = (!skipped && cbpc > 0) ? 2 : 0;
-    } else if (unit < 7) {
-        first_slot = unit == 5 ? 19 : 23;
-        n_slots = (!skipped && cbpc == 2) ? 4 : 0;
-    }
-    if (unit == 0) {
-        if (mx == 0 && my == srow) emit_slice_header(&bs, mb, S, item, B);
-        const int slice_last = B.slice_first_row[B.row_slice[my] + 1] * g.mbw - 1;
-        if (!skipped || mb == slice_last) {
-            const uint32_t run = skip_run_before(mask, mb, srow * g.mbw);
+    const venc_mbinfo *infos = B.mbinfo + (size_t)v * g.nmb;
+    const unsigned long long *mask = B.codedmask + ((size_t)v * g.n_slices + s) * B.ent_wps;
+    const int mb_seg = first + j * ENT_SEG_MBS;
+    /* ---- headers */
+    for (uint32_t k = tid; k < n_h; k += ENT_THREADS) {
+        const uint32_t e = cls[k], rank = e >> 13;
+        const int mb = mb_seg + (int)((e >> 5) & 255u);
+        const int my = mb / g.mbw, mx = mb - my * g.mbw;
+        venc_bitsink4 bs;
+        venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mb) * VENC_MB_WORDS);
+        const uint32_t rec = ((const uint32_t *)(infos + mb))[6];
+        const int cbp = (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4);
+        const int rel = mb - first;
+        const bool skipped = !((mask[rel >> 6] >> (rel & 63)) & 1ull);
+        if (rel == 0) emit_slice_header(&bs, mb, S, v, B);
+        if (!skipped || mb == last - 1) {
+            const uint32_t run = skip_run_before(mask, rel);
             if (skipped)
                 venc_bs_ue(&bs, run + 1u); /* a slice that ends in skipped macroblocks carries their count as a last mb_skip_run */
             else
-                emit_p_mb_header(&bs, g, B.mvsad + (size_t)item * g.nmb, mb, mx, my, aL, aT, cbp, run);
+                emit_p_mb_header(&bs, g, B.mvsad + (size_t)v * g.nmb, mb, mx, my, mx > 0, my > srow, cbp, run);
         }
+        s_len[rank] = (uint16_t)venc_bs_flush(&bs);
+        head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
     }
-    for (int k = 0; k < n_slots; k++) {
-        const int slot = first_slot + k;
-        int first = 0, maxc = 16, nC = 0, own_idx = 0;
-        bool has_nnz_entry = true;
-        if (slot < 16) {
-            own_idx = blk_y(slot) * 4 + blk_x(slot);
-        } else if (slot < 19) {
-            maxc = 4;
-            nC = -1;
-            has_nnz_entry = false;
-        } else {
-            first = 1, maxc = 15;
-            own_idx = 16 + (slot - 19);
-        }
-        if (nC == 0) {
-            int ia, ib;
-            bool inA, inB;
-            if (slot < 16) {
-                const int bx = blk_x(slot), by = blk_y(slot);
-                inA = bx > 0, inB = by > 0;
-                ia = inA ? by * 4 + bx - 1 : by * 4 + 3;
-                ib = inB ? (by - 1) * 4 + bx : 12 + bx;
-            } else {
-                const int kk = (slot - 19) & 3, nb = 16 + 4 * ((slot - 19) >> 2);
-                const int bx = kk & 1, by = kk >> 1;
-                inA = bx > 0, inB = by > 0;
-                ia = inA ? nb + 2 * by : nb + 2 * by + 1;
-                ib = inB ? nb + bx : nb + 2 + bx;
-            }
-            const int nA = inA ? info_byte(o0, o1, ia) : info_byte(l0, l1, ia);
-            const int nB = inB ? info_byte(o0, o1, ib) : info_byte(t0, t1, ib);
-            nC = venc_nc(inA || aL, nA, inB || aT, nB);
+    /* ---- blocks that hold a level (and the chroma DC blocks) */
+    for (uint32_t k = n_h + tid; k < n_hn; k += ENT_THREADS) {
+        const uint32_t e = cls[k], rank = e >> 13;
+        const int slot = (int)(e & 31u), mb = mb_seg + (int)((e >> 5) & 255u);
+        const int my = mb / g.mbw, mx = mb - my * g.mbw;
+        const int lslot = slot <= 16 ? slot - 1 : slot;
+        int firstc, maxc;
+        const int nC = ent_block_nc(g, infos, mb, lslot, mx > 0, my > srow, firstc, maxc);
+        const int16_t *lv = B.levels + ((size_t)v * g.nmb + mb) * VENC_MB_COEFS + lslot * 16;
+        const uint4 a = ((const uint4 *)lv)[0];
+        strip[0] = a.x, strip[1] = a.y, strip[2] = a.z, strip[3] = a.w;
+        uint32_t wds[8] = {a.x, a.y, a.z, a.w, 0u, 0u, 0u, 0u};
+        if (maxc != 4) { /* chroma DC records hold 4 levels: one 16-byte load is enough */
+            const uint4 bq = ((const uint4 *)lv)[1];
+            strip[4] = bq.x, strip[5] = bq.y, strip[6] = bq.z, strip[7] = bq.w;
+            wds[4] = bq.x, wds[5] = bq.y, wds[6] = bq.z, wds[7] = bq.w;
         }
         uint32_t nz = 0;
-        if (!(has_nnz_entry && info_byte(o0, o1, own_idx) == 0)) { /* empty blocks were never written */
-            const uint4 a = ((const uint4 *)(lv_mb + slot * 16))[0];
-            strip[0] = a.x, strip[1] = a.y, strip[2] = a.z, strip[3] = a.w;
-            uint32_t wds[8] = {a.x, a.y, a.z, a.w, 0u, 0u, 0u, 0u};
-            if (maxc != 4) { /* chroma DC records hold 4 levels: one 16-byte load is enough */
-                const uint4 bq = ((const uint4 *)(lv_mb + slot * 16))[1];
-                strip[4] = bq.x, strip[5] = bq.y, strip[6] = bq.z, strip[7] = bq.w;
-                wds[4] = bq.x, wds[5] = bq.y, wds[6] = bq.z, wds[7] = bq.w;
-            }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                nz |= (uint32_t)((wds[i] & 0xffffu) != 0u) << (2 * i);
-                nz |= (uint32_t)((wds[i] >> 16) != 0u) << (2 * i + 1);
-            }
-            nz = (nz >> first) & ((1u << maxc) - 1u);
+        for (int i = 0; i < 8; i++) {
+            nz |= (uint32_t)((wds[i] & 0xffffu) != 0u) << (2 * i);
+            nz |= (uint32_t)((wds[i] >> 16) != 0u) << (2 * i + 1);
         }
-        venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, first, maxc, nC, s_tab);
+        nz = (nz >> firstc) & ((1u << maxc) - 1u);
+        venc_bitsink4 bs;
+        venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mb) * VENC_MB_WORDS + slot * VENC_LANE_WORDS);
+        venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, firstc, maxc, nC, s_tab);
+        s_len[rank] = (uint16_t)venc_bs_flush(&bs);
+        head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
     }
-    ubits[unit] = (uint16_t)venc_bs_flush(&bs);
-  }
+    /* ---- blocks without a level inside a coded 8x8 block / coded chroma AC: coeff_token of TotalCoeff 0 for their nC */
+    for (uint32_t k = n_hn + tid; k < count; k += ENT_THREADS) {
+        const uint32_t e = cls[k], rank = e >> 13;
+        const int slot = (int)(e & 31u), mb = mb_seg + (int)((e >> 5) & 255u);
+        const int my = mb / g.mbw, mx = mb - my * g.mbw;
+        int firstc, maxc;
+        const int nC = ent_block_nc(g, infos, mb, slot <= 16 ? slot - 1 : slot, mx > 0, my > srow, firstc, maxc);
+        const uint32_t tok = s_tab[VENC_TAB_TOKEN + (nC < 2 ? 0 : nC < 4 ? 68 : nC < 8 ? 136 : 204)];
+        const uint32_t len = tok >> 8;
+        s_len[rank] = (uint16_t)len;
+        head[rank] = make_uint4((tok & 0xffu) << (32u - len), 0u, 0u, 0u);
+    }
+    __syncthreads();
+    /* ---- bit offsets inside the segment: exclusive scan of the lengths in rank order */
+    uint32_t base_bits = 0;
+    int phase = 0;
+    for (uint32_t k0 = 0; k0 < count; k0 += ENT_THREADS, phase ^= 1) {
+        const uint32_t k = k0 + (uint32_t)tid;
+        const uint32_t bits = k < count ? (uint32_t)s_len[k] : 0u;
+        const uint32_t incl = wave_scan_incl(bits);
+        if ((tid & 63) == 63) s_wtot[phase][tid >> 6] = incl;
+        __syncthreads();
+        uint32_t woff = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < ENT_THREADS / 64; w++) {
+            const uint32_t t = s_wtot[phase][w];
+            woff += w < (tid >> 6) ? t : 0u;
+            tot += t;
+        }
+        if (k < count) off[k] = base_bits + woff + incl - bits;
+        base_bits += tot;
+    }
+    if (tid == 0) {
+        off[count] = base_bits;
+        B.seg_bits[seg] = base_bits;
+    }
+}
+
+/* ================================================================== k_pack_p
+ * grid as k_skip2.  Output word w of a slice (stream bits [32 w, 32 w + 32)) belongs to the segment that holds bit 32 w.  A
+ * block zeroes an LDS window of its words, every lane ORs its entries' strings into it at their bit offsets (MSB first; strings
+ * are zero beyond their length), the first wave adds what the block's last word needs from the following segments' first entries,
+ * and the window leaves as coalesced stores.  The slice's last segment appends rbsp_stop_one_bit. */
+#define PACK_P_WORDS 1024
+/* ORs bits [o, o + len) of a slice (an entry's string: words 0 .. 3 in h, the rest at spill[4 ..]) into words [w_lo, w_hi) held at win[w - w_lo] */
+DEVFN void ent_or_into(uint32_t *win, uint32_t w_lo, uint32_t w_hi, uint32_t o, uint32_t len, const uint4 &h, const uint32_t *spill) {
+    const uint32_t nw = (len + 31u) >> 5, sh = o & 31u;
+    uint32_t t = o >> 5;
+    for (uint32_t i = 0; i < nw; i++, t++) {
+        if (t + 1u < w_lo) continue;
+        if (t >= w_hi) break;
+        const uint32_t src = i == 0 ? h.x : i == 1 ? h.y : i == 2 ? h.z : i == 3 ? h.w : spill[i];
+        if (t >= w_lo && (src >> sh)) atomicOr(&win[t - w_lo], src >> sh);
+        if (sh && t + 1u >= w_lo && t + 1u < w_hi && (src << (32u - sh))) atomicOr(&win[t + 1u - w_lo], src << (32u - sh));
+    }
+}
+
+__global__ __launch_bounds__(ENT_THREADS) void k_pack_p(venc_geom g, venc_bufs B, venc_step S, venc_slice_out *slice_dev) {
+    __shared__ uint32_t s_win[PACK_P_WORDS];
+    __shared__ uint32_t s_sl_bits[VENC_MAX_SLICES]; /* bits of the band's slices */
+    __shared__ uint32_t s_sl_off[VENC_MAX_SLICES];  /* byte offset of every slice of the picture */
+    __shared__ uint32_t s_segoff;                   /* bits of this slice's segments before this one */
+    const int v = blockIdx.z, sb = blockIdx.y, s = S.slice0 + sb, j = blockIdx.x, tid = threadIdx.x;
+    const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
+    const int nseg = (last - first + ENT_SEG_MBS - 1) / ENT_SEG_MBS;
+    const bool table_block = j == 0 && sb == 0; /* this block also writes the picture's slice table */
+    if (j >= nseg) return;
+    /* ---- every block sums the segment totals of the band's slices itself: slice lengths, byte offsets, its own bit offset */
+    const int band_slices = S.slice1 - S.slice0;
+    for (int q = tid; q < band_slices; q += ENT_THREADS) {
+        const int sq = S.slice0 + q;
+        const int nq = ((B.slice_first_row[sq + 1] - B.slice_first_row[sq]) * g.mbw + ENT_SEG_MBS - 1) / ENT_SEG_MBS;
+        const uint32_t *sbq = B.seg_bits + ent_seg(g, B, v, sq, 0);
+        uint32_t acc = 0;
+        for (int jj = 0; jj < nq; jj++) {
+            if (q == sb && jj == j) s_segoff = acc;
+            acc += sbq[jj];
+        }
+        s_sl_bits[q] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t byte_off = 0;
+        for (int k = 0; k < g.n_slices; k++) { /* slices of other bands: empty entries */
+            const bool mine = k >= S.slice0 && k < S.slice1;
+            const uint32_t nbytes = mine ? (s_sl_bits[k - S.slice0] + 1 + 7) >> 3 : 0u;
+            s_sl_off[k] = byte_off;
+            byte_off += (nbytes + 3u) & ~3u;
+        }
+        if (table_block) {
+            uint8_t *slot = B.out_hdr + (size_t)S.out_slot[v] * B.out_hdr_stride;
+            venc_slice_out *host_tab = (venc_slice_out *)(slot + sizeof(venc_out_header));
+            for (int k = 0; k < g.n_slices; k++) {
+                const bool mine = k >= S.slice0 && k < S.slice1;
+                const uint32_t nbits = mine ? s_sl_bits[k - S.slice0] : 0u;
+                const venc_slice_out so = {s_sl_off[k], mine ? (nbits + 1 + 7) >> 3 : 0u, nbits, 0};
+                slice_dev[(size_t)v * g.n_slices + k] = so;
+                host_tab[k] = so;
+            }
+            const venc_out_header h = {byte_off, (uint32_t)g.n_slices, byte_off > B.out_cap ? 1u : 0u, 0};
+            *(venc_out_header *)slot = h;
+        }
+    }
+    __syncthreads();
+    const uint32_t T = s_sl_bits[sb], nbytes = (T + 1 + 7) >> 3, byte_off = s_sl_off[s];
+    const size_t seg = ent_seg(g, B, v, s, j);
+    const uint32_t count = min(B.ent_count[4 * seg], B.ent_cap);
+    const uint32_t *list = B.ent_list + seg * B.ent_cap;
+    const uint4 *head = B.ent_head + seg * B.ent_cap;
+    const uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
+    const bool last_seg = j == nseg - 1;
+    const uint32_t begin = s_segoff, seg_end = begin + B.seg_bits[seg];
+    const uint32_t end = last_seg ? nbytes * 8u : seg_end; /* the words this block owns start in [begin, end) */
+    uint32_t *out = (uint32_t *)(B.out_data + (size_t)S.out_slot[v] * B.out_data_stride + byte_off);
+    const uint32_t *mbb = B.mbbits + (size_t)v * g.nmb * VENC_MB_WORDS;
+    for (uint32_t w0 = (begin + 31u) >> 5; 32u * w0 < end; w0 += PACK_P_WORDS) {
+        const uint32_t w1 = min(w0 + (uint32_t)PACK_P_WORDS, (end + 31u) >> 5); /* owned words of this window: [w0, w1) */
+        __syncthreads();
+        for (uint32_t q = tid; q < w1 - w0; q += ENT_THREADS) s_win[q] = 0;
+        __syncthreads();
+        for (uint32_t k = tid; k < count; k += ENT_THREADS) {
+            const uint32_t o = begin + off[k], len = off[k + 1] - off[k];
+            if (len == 0 || o + len <= 32u * w0 || o >= 32u * w1) continue;
+            const uint32_t e = list[k];
+            ent_or_into(s_win, w0, w1, o, len, head[k], mbb + (size_t)(e >> 5) * VENC_MB_WORDS + (e & 31u) * VENC_LANE_WORDS);
+        }
+        /* the window's last word may run on into the following segments (never past the slice: the last segment ends it) */
+        if (!last_seg && 32u * w1 > seg_end && tid < 64) {
+            uint32_t obase = seg_end;
+            for (int jj = j + 1; jj < nseg && obase < 32u * w1; jj++) {
+                const size_t sg = ent_seg(g, B, v, s, jj);
+                const uint32_t cn = min(B.ent_count[4 * sg], B.ent_cap);
+                const uint32_t *of = B.ent_off + sg * (B.ent_cap + 4);
+                for (uint32_t k = tid; k < cn; k += 64) { /* (an entry is at least one bit: the first 32 cover the word) */
+                    const uint32_t o = obase + of[k], len = of[k + 1] - of[k];
+                    if (__ballot(o < 32u * w1) == 0ull) break;
+                    if (len == 0 || o >= 32u * w1) continue;
+                    const uint32_t e = B.ent_list[sg * B.ent_cap + k];
+                    ent_or_into(s_win, w0, w1, o, len, B.ent_head[sg * B.ent_cap + k], mbb + (size_t)(e >> 5) * VENC_MB_WORDS + (e & 31u) * VENC_LANE_WORDS);
+                }
+                obase += B.seg_bits[sg];
+            }
+        }
+        if (last_seg && tid == 0 && (T >> 5) >= w0 && (T >> 5) < w1) atomicOr(&s_win[(T >> 5) - w0], 0x80000000u >> (T & 31u)); /* rbsp_stop_one_bit */
+        __syncthreads();
+        for (uint32_t q = tid; q < w1 - w0; q += ENT_THREADS) {
+            if (byte_off + 4u * (w0 + q + 1u) > B.out_cap) break;
+            out[w0 + q] = __builtin_bswap32(s_win[q]);
+        }
+    }
+}
+
+/* debug / tests (venc_debug_read selector 3): bits per macroblock of a P picture = the sum of its entries' lengths */
+__global__ __launch_bounds__(ENT_THREADS) void k_entry_mbbits(venc_geom g, venc_bufs B, venc_step S, int v) {
+    const int s = S.slice0 + blockIdx.y, j = blockIdx.x;
+    const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
+    if (j * ENT_SEG_MBS >= last - first) return;
+    const size_t seg = ent_seg(g, B, v, s, j);
+    const uint32_t count = min(B.ent_count[4 * seg], B.ent_cap);
+    const uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
+    for (uint32_t k = threadIdx.x; k < count; k += ENT_THREADS) atomicAdd(&B.mbnbits[(size_t)v * g.nmb + (B.ent_list[seg * B.ent_cap + k] >> 5)], off[k + 1] - off[k]);
 }

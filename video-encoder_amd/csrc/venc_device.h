@@ -194,6 +194,51 @@ VENC_DEV int venc_bs_flush(venc_bitsink *b) {
     if (b->nacc > 0) b->w[b->nwords] = (uint32_t)(b->acc << (32 - b->nacc));
     return venc_bs_bits(b);
 }
+/* The same sink with its first four words in REGISTERS (round 4: the syntax entries of P pictures, venc_cavlc_p.hip).  An entry
+ * -- a macroblock header or one 4x4 block -- is 10-30 bits on ordinary content, so its whole string leaves the lane as ONE
+ * 16-byte store into a dense array (coalesced across the wave) instead of a word here and there in a 2 KB region per macroblock
+ * (what made k_pack read 65x the bytes it wrote).  Words 4 .. 15 (an entry beyond 128 bits: a dense block at a fine quantiser) go
+ * to spill[word index].  h0 .. h3 are only ever addressed by constants (selects), so they stay in registers. */
+typedef struct {
+    uint32_t h0, h1, h2, h3;
+    uint32_t *spill;
+    uint64_t acc;
+    int nacc, nwords;
+} venc_bitsink4;
+VENC_DEV void venc_bs4_init(venc_bitsink4 *b, uint32_t *spill) {
+    b->h0 = b->h1 = b->h2 = b->h3 = 0u;
+    b->spill = spill;
+    b->acc = 0;
+    b->nacc = 0;
+    b->nwords = 0;
+}
+VENC_DEV void venc_bs4_word(venc_bitsink4 *b, uint32_t w) {
+    const int n = b->nwords;
+    if (n < 4) {
+        b->h0 = n == 0 ? w : b->h0;
+        b->h1 = n == 1 ? w : b->h1;
+        b->h2 = n == 2 ? w : b->h2;
+        b->h3 = n == 3 ? w : b->h3;
+    } else
+        b->spill[n] = w;
+    b->nwords = n + 1;
+}
+VENC_DEV void venc_bs_put(venc_bitsink4 *b, uint32_t code, int len) { /* as above */
+    b->acc = (b->acc << len) | (uint64_t)code;
+    b->nacc += len;
+    if (b->nacc >= 32) {
+        venc_bs4_word(b, (uint32_t)(b->acc >> (b->nacc - 32)));
+        b->nacc -= 32;
+    }
+}
+VENC_DEV int venc_bs_flush(venc_bitsink4 *b) { /* the partial last word left-aligned (nwords does not count it); returns total bits */
+    const int bits = 32 * b->nwords + b->nacc;
+    if (b->nacc > 0) {
+        venc_bs4_word(b, (uint32_t)(b->acc << (32 - b->nacc)));
+        b->nwords--;
+    }
+    return bits;
+}
 VENC_DEV int venc_ilog2(uint32_t v) { /* floor(log2(v)), v > 0 */
 #if defined(__HIPCC__)
     return 31 - __clz((int)v);
@@ -208,11 +253,13 @@ VENC_DEV int venc_popc(uint32_t v) {
     return __builtin_popcount(v);
 #endif
 }
-VENC_DEV void venc_bs_ue(venc_bitsink *b, uint32_t v) {
+template <class BS>
+VENC_DEV void venc_bs_ue(BS *b, uint32_t v) {
     int k = venc_ilog2(v + 1);
     venc_bs_put(b, v + 1, 2 * k + 1); /* k zeros followed by the (k+1)-bit value */
 }
-VENC_DEV void venc_bs_se(venc_bitsink *b, int v) { venc_bs_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
+template <class BS>
+VENC_DEV void venc_bs_se(BS *b, int v) { venc_bs_ue(b, v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }
 
 /* ---------------------------------------------------------------- CAVLC block
  * c[]: the block's levels in scan order; the block occupies scan positions
@@ -327,7 +374,8 @@ VENC_DEV uint32_t venc_nzmask_mem(const int16_t *c, int first, int max_coef) {
     return nz;
 }
 
-VENC_DEV int venc_cavlc_block_mem(venc_bitsink *b, const int16_t *c, uint32_t nz, int first, int max_coef, int nC,
+template <class BS>
+VENC_DEV int venc_cavlc_block_mem(BS *b, const int16_t *c, uint32_t nz, int first, int max_coef, int nC,
                                   const uint16_t *tab) {
     const int total = venc_popc(nz);
     int t1 = 0;

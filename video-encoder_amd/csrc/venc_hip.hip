@@ -155,7 +155,8 @@ struct venc_ctx {
     uint8_t *d_row_slice;
     uint16_t *d_rank, *d_cand;
     int intra_waves;
-    int unit_phase;   /* which of the two sets of unit counters the next P batch fills */
+    int last_batch_p; /* the last entropy batch coded P pictures (venc_debug_read derives their per-macroblock bits from the entries) */
+    venc_step last_batch_S;
     int me_xcd;       /* VENC_ME_XCD=1: XCD-aware tile order in k_me_pool (less fabric traffic, slightly slower) */
     int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
     int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
@@ -307,13 +308,16 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.mbinfo);
     (void)hipFree(c->b.mbbits);
     (void)hipFree(c->b.mbnbits);
-    (void)hipFree(c->b.ubits);
     (void)hipFree(c->b.mboff);
     (void)hipFree(c->b.codedmask);
-    (void)hipFree(c->b.unit_list);
+    (void)hipFree(c->b.ent_list);
+    (void)hipFree(c->b.ent_cls);
+    (void)hipFree(c->b.ent_count);
+    (void)hipFree(c->b.ent_head);
+    (void)hipFree(c->b.ent_off);
+    (void)hipFree(c->b.seg_bits);
     (void)hipFree(c->b.slice_bits);
     (void)hipFree(c->b.scan_done);
-    (void)hipFree(c->b.unit_count);
     (void)hipFree(c->b.refsum);
     (void)hipFree(c->b.me_flag);
     (void)hipFree(c->b.me_cnt);
@@ -568,15 +572,27 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMemset(b.mbinfo, 0, VENC_RING * G * nmb * sizeof(venc_mbinfo)));
     OPEN_OK(hipMalloc(&b.mbbits, GV * nmb * VENC_MB_WORDS * 4));
     OPEN_OK(hipMalloc(&b.mbnbits, GV * nmb * 4));
-    OPEN_OK(hipMalloc(&b.ubits, GV * nmb * 8 * 2));
     OPEN_OK(hipMalloc(&b.mboff, GV * nmb * 4));
-    OPEN_OK(hipMalloc(&b.codedmask, GV * ((nmb + 63) / 64) * 8));
-    OPEN_OK(hipMalloc(&b.unit_list, GV * nmb * 7 * 4));
+    {
+        /* P pictures: segments of 256 macroblocks of a slice (venc_cavlc_p.hip) */
+        const int slice_mbs = maxrows * g.mbw;
+        b.ent_spp = (slice_mbs + ENT_SEG_MBS - 1) / ENT_SEG_MBS;
+        b.ent_wps = 4 * b.ent_spp;
+        b.ent_cap = (uint32_t)(ENT_PER_MB * (slice_mbs < ENT_SEG_MBS ? slice_mbs : ENT_SEG_MBS));
+        const size_t nseg = GV * g.n_slices * b.ent_spp;
+        OPEN_OK(hipMalloc(&b.codedmask, GV * g.n_slices * b.ent_wps * 8));
+        OPEN_OK(hipMalloc(&b.ent_list, nseg * b.ent_cap * 4));
+        OPEN_OK(hipMalloc(&b.ent_cls, nseg * b.ent_cap * 4));
+        OPEN_OK(hipMalloc(&b.ent_count, nseg * 16));
+        OPEN_OK(hipMemset(b.ent_count, 0, nseg * 16));
+        OPEN_OK(hipMalloc(&b.ent_head, nseg * b.ent_cap * sizeof(uint4)));
+        OPEN_OK(hipMalloc(&b.ent_off, nseg * (b.ent_cap + 4) * 4));
+        OPEN_OK(hipMalloc(&b.seg_bits, nseg * 4));
+        OPEN_OK(hipMemset(b.seg_bits, 0, nseg * 4));
+    }
     OPEN_OK(hipMalloc(&b.slice_bits, GV * VENC_MAX_SLICES * 4));
     OPEN_OK(hipMalloc(&b.scan_done, GV * VENC_COUNTER_STRIDE * 4));
     OPEN_OK(hipMemset(b.scan_done, 0, GV * VENC_COUNTER_STRIDE * 4));
-    OPEN_OK(hipMalloc(&b.unit_count, 2 * GV * VENC_COUNTER_STRIDE * 4));
-    OPEN_OK(hipMemset(b.unit_count, 0, 2 * GV * VENC_COUNTER_STRIDE * 4));
     b.refsum_stride = (g.cw + 17 + 15) & ~15;
     b.refsum_item = (size_t)b.refsum_stride * (g.ch + 25);
 #ifdef VENC_LEGACY_KERNELS
@@ -1132,9 +1148,6 @@ static int entropy_flush(venc_ctx *c) {
     b.levels = c->b.levels + (size_t)rs0 * GN * VENC_MB_COEFS;
     b.mbinfo = c->b.mbinfo + (size_t)rs0 * GN;
     if (c->cfg.rc_mode) b.qp_cur = c->d_qp_ring + (size_t)(c->eb_first_step % VENC_QP_RING) * c->b.max_items;
-    b.unit_count = c->b.unit_count + (size_t)c->unit_phase * c->b.vcap * VENC_COUNTER_STRIDE;
-    b.unit_count_next = c->b.unit_count + (size_t)(c->unit_phase ^ 1) * c->b.vcap * VENC_COUNTER_STRIDE;
-    if (!is_idr) c->unit_phase ^= 1;
     hipStream_t s1 = c->stream, s2 = c->overlap ? c->stream2 : c->stream;
     const int hi = c->bh_next;
     if (c->overlap) {
@@ -1176,28 +1189,34 @@ static int entropy_flush(venc_ctx *c) {
     if (is_idr)
         hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, nv), dim3(256), 0, s2, g, b, S);
     else {
-        hipLaunchKernelGGL(k_skip, dim3((S.mb1 - (S.mb0 & ~63) + 255) / 256, 1, nv), dim3(256), 0, s2, g, b, S); /* P_Skip decisions */
-        /* one lane per listed unit: at most 7 per macroblock, about 1.2 on ordinary content -- blocks loop over the list */
-        const int cav_threads = (long long)band_mbs * G <= 131072 ? CAVLC_P_MAX_THREADS : 512;
-        const int cav_need = (7 * band_mbs + cav_threads - 1) / cav_threads;
-        const int cav_blocks = cav_need < CAVLC_P_BLOCK_LANES / cav_threads ? cav_need : CAVLC_P_BLOCK_LANES / cav_threads;
-        hipLaunchKernelGGL(k_cavlc_p, dim3(cav_blocks, 1, nv), dim3(cav_threads), (size_t)cav_threads * 36, s2, g, b, S);
+        /* P pictures (venc_cavlc_p.hip): one block per segment of 256 macroblocks of a slice in all three kernels */
+        const dim3 eg(c->b.ent_spp, band_slices, nv);
+        hipLaunchKernelGGL(k_skip2, eg, dim3(ENT_SEG_MBS), 0, s2, g, b, S);
+        hipLaunchKernelGGL(k_cavlc_p2, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (((size_t)c->b.ent_cap * 2 + 15) & ~(size_t)15), s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {
-        /* the ring slots of the batch are free again once these kernels are done (k_scan and k_pack read the chain's own buffers) */
+        /* the ring slots of the batch are free again once these kernels are done (k_scan and the pack kernels read the chain's own buffers) */
         for (int k = 0; k < n_steps; k++) {
             HIP_OK(hipEventRecord(c->ev_side[rs0 + k], s2));
             c->side_step[rs0 + k] = c->eb_first_step + k;
         }
     }
-    prof_begin(c, KID_SCAN, s2);
-    hipLaunchKernelGGL(k_scan, dim3(band_slices, nv), dim3(64 * SCAN_WAVES), 0, s2, g, b, S, c->d_slice);
-    prof_end(c, s2);
-    prof_begin(c, KID_PACK, s2);
-    hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, band_slices, nv), dim3(256), 0, s2, g, b, S,
-                       (const venc_slice_out *)c->d_slice);
-    prof_end(c, s2);
+    if (is_idr) {
+        prof_begin(c, KID_SCAN, s2);
+        hipLaunchKernelGGL(k_scan, dim3(band_slices, nv), dim3(64 * SCAN_WAVES), 0, s2, g, b, S, c->d_slice);
+        prof_end(c, s2);
+        prof_begin(c, KID_PACK, s2);
+        hipLaunchKernelGGL(k_pack, dim3((c->max_slice_mbs + PACK_MBS - 1) / PACK_MBS, band_slices, nv), dim3(256), 0, s2, g, b, S,
+                           (const venc_slice_out *)c->d_slice);
+        prof_end(c, s2);
+    } else {
+        prof_begin(c, KID_PACK, s2);
+        hipLaunchKernelGGL(k_pack_p, dim3(c->b.ent_spp, band_slices, nv), dim3(ENT_THREADS), 0, s2, g, b, S, c->d_slice);
+        prof_end(c, s2);
+    }
+    c->last_batch_p = !is_idr;
+    c->last_batch_S = S;
     HIP_OK(hipGetLastError());
     /* tickets handed out while the batch was open complete here */
     for (int i = 0; i < c->eb_nt; i++) HIP_OK(hipEventRecord(c->ev[c->eb_tickets[i] % c->n_events], s2));
@@ -1469,7 +1488,19 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
             break;
         case 1: src = c->b.levels + (lp_off + item) * nmb * VENC_MB_COEFS, n = nmb * VENC_MB_COEFS * 2; break;
         case 2: src = c->b.mbinfo + (lp_off + item) * nmb, n = nmb * sizeof(venc_mbinfo); break;
-        case 3: src = c->b.mbnbits + item * nmb, n = nmb * 4; break;
+        case 3:
+            if (c->last_batch_p) { /* P pictures: the sum of each macroblock's entry lengths (the entropy chain keeps no per-macroblock count) */
+                HIP_OK(hipMemset(c->b.mbnbits + item * nmb, 0, nmb * 4));
+                hipLaunchKernelGGL(k_entry_mbbits, dim3(c->b.ent_spp, c->last_batch_S.slice1 - c->last_batch_S.slice0, 1), dim3(ENT_THREADS), 0, 0, g, c->b, c->last_batch_S, item);
+                HIP_OK(hipDeviceSynchronize());
+            }
+            src = c->b.mbnbits + item * nmb, n = nmb * 4;
+            break;
+        case 16: src = c->b.ent_count + (size_t)item * g.n_slices * c->b.ent_spp * 4, n = (size_t)g.n_slices * c->b.ent_spp * 16; break; /* P pictures: per segment entries, headers, blocks with a level, - */
+        case 18: src = c->b.ent_list + (size_t)item * g.n_slices * c->b.ent_spp * c->b.ent_cap, n = (size_t)g.n_slices * c->b.ent_spp * c->b.ent_cap * 4; break;
+        case 19: src = c->b.ent_off + (size_t)item * g.n_slices * c->b.ent_spp * (c->b.ent_cap + 4), n = (size_t)g.n_slices * c->b.ent_spp * (c->b.ent_cap + 4) * 4; break;
+        case 20: src = c->b.ent_cls + (size_t)item * g.n_slices * c->b.ent_spp * c->b.ent_cap, n = (size_t)g.n_slices * c->b.ent_spp * c->b.ent_cap * 4; break;
+        case 17: src = c->b.seg_bits + (size_t)item * g.n_slices * c->b.ent_spp, n = (size_t)g.n_slices * c->b.ent_spp * 4; break;  /* ... and bits */
         case 4: src = rec, n = (size_t)g.cw * g.ch; break;
         case 5: src = rec + (size_t)g.cw * g.ch, n = (size_t)g.cw * g.ch / 4; break;
         case 6: src = rec + (size_t)g.cw * g.ch * 5 / 4, n = (size_t)g.cw * g.ch / 4; break;

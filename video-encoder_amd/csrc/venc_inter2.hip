@@ -329,8 +329,13 @@ DEVFN void inter_luma_mb(const venc_geom &g, const venc_bufs &B, const venc_step
 }
 
 /* chroma transform of macroblock mb: 8 lanes, lane & 3 = block, (lane >> 2) & 1 = plane, lane & 56 = group of 8 */
+struct chroma_listed { /* a chroma block that holds an AC level, between the two passes of a k_inter_fused block (LDS) */
+    uint4 cq, pq; /* current and predicted rows, four samples per dword */
+    int d0;       /* its dequantised DC (the 2x2 transform spans the plane's four blocks: decided in the first pass) */
+    uint32_t id;  /* mb << 3 | plane << 2 | block */
+};
 DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy,
-                           const venc_qparams &qc) {
+                           const venc_qparams &qc, chroma_listed *cl, uint32_t *cl_count) {
     const int k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
     const int mx = mb % g.mbw, my = mb / g.mbw;
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
@@ -403,7 +408,7 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
         for (int x = 0; x < 4; x++) p[4 * y + x] = (hs[y][x] + (fy ? hs[y + 1][x] : hs[y][x]) + 2) >> 2;
     }
 
-    int res[16], w[16], lv[16], rr[16], nnz;
+    int res[16], w[16];
 #pragma unroll
     for (int y = 0; y < 4; y++) {
         res[4 * y] = byte_sub_int<0>(cq[y], p[4 * y]);
@@ -427,27 +432,27 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
         fc += (__popc(k & qi) & 1) ? -v : v;
     }
     const int d0 = venc_dequant_chroma_dc(fc, &qc);
-    if (__ballot(valid && !blk_all_zero<true>(w, qc)) == 0ull) {
-        /* no AC level in any block of the wave: the inverse transform of a lone DC is (d0 + 32) >> 6 in every sample */
-        const int r0 = (d0 + 32) >> 6;
-        nnz = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) lv[i] = 0, rr[i] = venc_clip_u8(p[i] + r0);
-    } else {
-        blk_quant_res<true>(w, qc, qc.f_inter, d0, lv, rr, nnz);
-#pragma unroll
-        for (int i = 0; i < 16; i++) rr[i] = venc_clip_u8(p[i] + rr[i]);
-    }
-
+    /* DEFERRED FORM (round 4, as the luma transform's since round 3): this pass only DECIDES.  A block without an AC level --
+     * 85-97 % of them -- is finished here: the inverse transform of a lone DC is (d0 + 32) >> 6 in every sample.  A block WITH one
+     * is listed in LDS (its current rows, its prediction packed, its DC) and coded by the first lanes of the block after a barrier
+     * (inter_chroma_listed).  Before, a wave took the short path only when all 64 of its blocks were empty, i.e. rarely where it
+     * mattered: 6.0 M vector instructions per 1080p step.  The exact zero test is the quantiser's own arithmetic (blk_all_zero), so
+     * listed <=> nnz > 0 and coded_block_pattern is known here. */
+    const bool nz = valid && !blk_all_zero<true>(w, qc);
+    const unsigned long long bal_ac = __ballot(nz), bal_dc = __ballot(valid && dclv != 0);
     int16_t *lv_mb = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS;
     venc_mbinfo *info = B.mbinfo + (size_t)item * g.nmb + mb;
     const int dc0 = __shfl(dclv, qbase | 0), dc1 = __shfl(dclv, qbase | 1), dc2 = __shfl(dclv, qbase | 2), dc3 = __shfl(dclv, qbase | 3);
-    const unsigned long long bal_ac = __ballot(nnz > 0), bal_dc = __ballot(dclv != 0);
+    const int pk = (plane - 1) * 4 + k;
     if (valid) {
-        const int pk = (plane - 1) * 4 + k;
-        if (nnz) store_levels(lv_mb + (19 + pk) * 16, lv);
-        info->nnz[16 + pk] = (uint8_t)nnz;
-        store_rec4x4(rec, wstride, px, py, rr);
+        if (!nz) {
+            const int r0 = (d0 + 32) >> 6;
+            int rr[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) rr[i] = venc_clip_u8(p[i] + r0);
+            info->nnz[16 + pk] = 0;
+            store_rec4x4(rec, wstride, px, py, rr);
+        }
         if (k == 0) {
             uint4 *dst = (uint4 *)(lv_mb + (16 + plane) * 16);
             dst[0] = make_uint4(((uint32_t)dc0 & 0xffffu) | ((uint32_t)dc1 << 16), ((uint32_t)dc2 & 0xffffu) | ((uint32_t)dc3 << 16), 0, 0);
@@ -457,6 +462,48 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
             info->cbpc = (uint8_t)(hac ? 2 : hdc ? 1 : 0);
         }
     }
+    if (nz) {
+        const uint32_t at = atomicAdd(cl_count, 1u);
+        chroma_listed e;
+        e.cq = make_uint4(cq[0], cq[1], cq[2], cq[3]);
+        uint32_t pp[4];
+#pragma unroll
+        for (int y = 0; y < 4; y++) pp[y] = (uint32_t)p[4 * y] | ((uint32_t)p[4 * y + 1] << 8) | ((uint32_t)p[4 * y + 2] << 16) | ((uint32_t)p[4 * y + 3] << 24);
+        e.pq = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+        e.d0 = d0;
+        e.id = ((uint32_t)mb << 3) | (uint32_t)pk;
+        cl[at] = e;
+    }
+}
+
+/* one listed chroma block, any lane: residual ... reconstruction, its levels and its count */
+DEVFN void inter_chroma_listed(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, const chroma_listed &e, const venc_qparams &qc) {
+    const int mb = (int)(e.id >> 3), pk = (int)(e.id & 7u), plane = 1 + (pk >> 2), k = pk & 3;
+    const int my = mb / g.mbw, mx = mb - my * g.mbw;
+    const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
+    int wstride;
+    uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);
+    const uint32_t cq[4] = {e.cq.x, e.cq.y, e.cq.z, e.cq.w}, pq[4] = {e.pq.x, e.pq.y, e.pq.z, e.pq.w};
+    int res[16], w[16], lv[16], rr[16], nnz;
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        res[4 * y] = byte_sub_byte<0>(cq[y], pq[y]);
+        res[4 * y + 1] = byte_sub_byte<1>(cq[y], pq[y]);
+        res[4 * y + 2] = byte_sub_byte<2>(cq[y], pq[y]);
+        res[4 * y + 3] = byte_sub_byte<3>(cq[y], pq[y]);
+    }
+    venc_fdct4(res, w);
+    blk_quant_res<true>(w, qc, qc.f_inter, e.d0, lv, rr, nnz);
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        rr[4 * y] = venc_clip_u8(int_add_byte<0>(rr[4 * y], pq[y]));
+        rr[4 * y + 1] = venc_clip_u8(int_add_byte<1>(rr[4 * y + 1], pq[y]));
+        rr[4 * y + 2] = venc_clip_u8(int_add_byte<2>(rr[4 * y + 2], pq[y]));
+        rr[4 * y + 3] = venc_clip_u8(int_add_byte<3>(rr[4 * y + 3], pq[y]));
+    }
+    store_levels(B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + (19 + pk) * 16, lv);
+    (B.mbinfo + (size_t)item * g.nmb + mb)->nnz[16 + pk] = (uint8_t)nnz;
+    store_rec4x4(rec, wstride, px, py, rr);
 }
 
 /* ================================================================== k_inter_fused
@@ -486,11 +533,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     venc_qparams ql, qc;
     step_qparams(g, B, S, item, ql, qc);
     if (bx >= n_luma) {
+        __shared__ chroma_listed s_cl[256];
+        __shared__ uint32_t s_cl_count;
+        if (tid == 0) s_cl_count = 0;
+        __syncthreads();
         const int mb_raw = S.mb0 + (bx - n_luma) * 32 + (tid >> 3);
         const bool valid = mb_raw < S.mb1;
         const int mb = valid ? mb_raw : S.mb1 - 1;
         const uint32_t m = mvs[mb];
-        inter_chroma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u), qc);
+        inter_chroma_mb(g, B, S, item, lane, mb, valid, (int)(int8_t)(m & 255u), (int)(int8_t)((m >> 8) & 255u), qc, s_cl, &s_cl_count);
+        __syncthreads();
+        if ((uint32_t)tid < s_cl_count) inter_chroma_listed(g, B, S, item, s_cl[tid], qc);
     } else {
         const int mb_raw = S.mb0 + bx * 16 + (tid >> 4);
         const bool valid = mb_raw < S.mb1;

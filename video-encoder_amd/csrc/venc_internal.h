@@ -9,7 +9,8 @@
  *   mvsad         [G][nmb] u32   = sad<<16 | (dy&255)<<8 | (dx&255)
  *   levels        [G][nmb][27][16] i16   (block order documented in include/venc_hip.h)
  *   mbinfo        [G][nmb] 32 B  = nnz[24] (16 luma raster, 4 Cb, 4 Cr), cbp, flags
- *   mbbits        [G][nmb][VENC_MB_WORDS] u32  MSB-first bit strings, one per syntax unit (unit u at word 64 u)
+ *   mbbits        [G][nmb][VENC_MB_WORDS] u32  I pictures: the macroblock's MSB-first bit string (k_cavlc); P pictures: words 4 .. 15 of
+ *                                              the rare entry beyond 128 bits, entry slot e at word 16 e (venc_cavlc_p.hip)
  *   mbnbits/mboff [G][nmb] u32
  *   refsum        [G][ch+25][cw+17 (padded)] u32 = S8(x,y) | S8(x+8,y)<<16 of the reference luma
  *   out headers (pinned host, device-mapped) [out_slots][header | slice table]
@@ -26,7 +27,6 @@
 #define VENC_MAX_SLICES 256
 #define VENC_MB_COEFS 432   /* 27 blocks x 16 */
 #define VENC_MB_WORDS 512   /* per-macroblock bit-string region: 8 units x 64 words (an I macroblock uses it as one string of <= 13312 bits) */
-#define VENC_UNIT_WORDS 64  /* P pictures: bit string of one syntax unit (at most four 4x4 blocks + the macroblock header: < 2048 bits) */
 #define VENC_LANE_WORDS 16  /* per-block private capacity: 512 bits >= 16 + 16*28 */
 #define VENC_ME_RANGE 16
 #define VENC_ME_CANDS 1089
@@ -110,10 +110,19 @@ typedef struct {
     uint32_t *mbnbits;
     uint16_t *ubits;            /* [G][nmb][8] bits of the macroblock's syntax units (k_cavlc*), turned into running ends by k_scan */
     uint32_t *mboff;
-    unsigned long long *codedmask; /* [G][(nmb + 63) / 64] P pictures: bit = macroblock is coded (not P_Skip), k_skip */
-    uint32_t *unit_list;        /* [G][nmb * 7] P pictures: non-empty syntax units, mb << 3 | unit (k_skip -> k_cavlc_p) */
-    uint32_t *unit_count;       /* [G][32] (one per 128-byte line) entries of unit_list; two counters alternate between P steps (the launcher sets both pointers) */
-    uint32_t *unit_count_next;
+    /* P pictures, round 4 (venc_cavlc_p.hip): a slice is cut into SEGMENTS of 256 macroblocks; segment (v, s, j) has index
+     * (v * n_slices + s) * ent_spp + j.  Per segment: its syntax entries in bitstream order (mb << 5 | slot), their bit strings'
+     * first four words, their bit offsets inside the segment (count + 1 of them), the segment's bits. */
+    unsigned long long *codedmask; /* [G][n_slices][ent_wps] bit = macroblock (slice-relative index) is coded (not P_Skip), k_skip2 */
+    uint32_t *ent_list;         /* [segments][ent_cap] bitstream order: mb << 5 | slot */
+    uint32_t *ent_cls;          /* [segments][ent_cap] sorted by kind (headers | blocks with a level | empty blocks): rank << 13 | macroblock of the segment << 5 | slot */
+    uint32_t *ent_count;        /* [segments][4] entries, headers, blocks with a level, - */
+    uint4 *ent_head;            /* [segments][ent_cap] */
+    uint32_t *ent_off;          /* [segments][ent_cap + 4] */
+    uint32_t *seg_bits;         /* [segments] */
+    uint32_t ent_cap;           /* entries a segment can hold: 27 x min(256, macroblocks of the largest slice) */
+    int ent_spp;                /* segments per slice (of the largest slice) */
+    int ent_wps;                /* mask words per slice: 4 x ent_spp */
     uint32_t *slice_bits;       /* [G][VENC_MAX_SLICES] bits of every slice of the step (k_scan: per-slice blocks -> the block that builds the table) */
     uint32_t *scan_done;        /* [G][32] k_scan arrival counters, one cache line each; zero between launches */
     const int *slice_first_row; /* n_slices + 1 */

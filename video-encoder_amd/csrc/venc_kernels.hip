@@ -8,11 +8,11 @@
  *   k_inter     a4.2/3/5  MC prediction, 4x4 core transform, quantisation, reconstruction (P; VENC_INTER=legacy)
  *   k_intra     a4.2/3/5  Intra16x16-DC wavefront per slice (I; VENC_INTRA=legacy)
  *   k_cavlc     a4.4  zig-zag/run-level entropy coding of I pictures, one lane per 4x4 block
- *   k_scan      a4.4  per-slice exclusive scan of the syntax units' bit lengths
- *   k_pack      a4.4  owner-gather bit packing straight into pinned host memory
+ *   k_scan      a4.4  I pictures: per-slice exclusive scan of the macroblocks' bit lengths
+ *   k_pack      a4.4  I pictures: owner-gather bit packing into the output slot
  *   k_band_copy a4.5  slice-parallel mode: rows of a band <-> exchange chunk
  * The shipped path's other kernels: venc_me3.hip (k_me_pool), venc_me2.hip (k_me_fix), venc_inter2.hip
- * (k_inter_fused), venc_intra2.hip (k_intra_fwd / k_intra_dc / k_intra_rec), venc_cavlc_p.hip (k_skip, k_cavlc_p).
+ * (k_inter_fused), venc_intra2.hip (k_intra_fwd / k_intra_dc / k_intra_rec), venc_cavlc_p.hip (P pictures: k_skip2, k_cavlc_p2, k_pack_p).
  *
  * Row references (a4.x) are SURVEY.md section 8a; the reference has no source
  * for any of these stages (they sit behind x264_encoder_encode(),
@@ -284,6 +284,11 @@ DEVFN void load_cur_rows(const uint8_t *cur, int cstride, int pw, int ph, int px
  * counts gives the concatenation offsets; strips are OR-ed into the
  * macroblock's bit string in LDS and streamed out to HBM. */
 #define CAVLC_MBS 8
+/* A lane's 16 levels go to LDS as eight dwords and the CAVLC coder reads them back as int16 (c[first + i]).  Through plain
+ * uint32_t / int16_t pointers that is a strict-aliasing violation the compiler may act on: in round 4's k_cavlc_p2 it moved the
+ * int16 loads ABOVE the dword stores and the coder saw the previous entry's levels (escape-coded garbage, different from run to
+ * run).  Stores through this type may alias anything. */
+typedef uint32_t __attribute__((may_alias)) lds_u32;
 
 /* byte idx (0..23) of a 32-byte macroblock record held in two uint4 */
 DEVFN int info_byte(const uint4 &a, const uint4 &b, int idx) {
@@ -302,7 +307,8 @@ DEVFN void load_levels(const int16_t *src, int c[16]) {
 }
 
 /* slice_header(), 7.3.3 -- written by the lane that codes the first macroblock of a slice */
-DEVFN void emit_slice_header(venc_bitsink *bs, int mb, const venc_step &S, int item, const venc_bufs &B) {
+template <class BS>
+DEVFN void emit_slice_header(BS *bs, int mb, const venc_step &S, int item, const venc_bufs &B) {
     venc_bs_ue(bs, (uint32_t)mb);
     venc_bs_ue(bs, S.is_idr ? 7u : 5u);
     venc_bs_ue(bs, 0);
@@ -367,7 +373,8 @@ DEVFN bool mb_is_p_skip(const venc_geom &g, const uint32_t *mvs, int mb, int mx,
 }
 
 /* mb_skip_run, mb_type, mvd, coded_block_pattern, mb_qp_delta of a P_L0_16x16 macroblock */
-DEVFN void emit_p_mb_header(venc_bitsink *bs, const venc_geom &g, const uint32_t *mvs, int mb, int mx, int my, bool aL, bool aT,
+template <class BS>
+DEVFN void emit_p_mb_header(BS *bs, const venc_geom &g, const uint32_t *mvs, int mb, int mx, int my, bool aL, bool aT,
                             int cbp, uint32_t skip_run) {
     (void)my;
     const uint32_t me = mvs[mb];
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
         /* AC / luma blocks with nnz = 0 were not written by the transform kernels */
         const bool empty = ((l32 >= 2 && l32 < 18) || (l32 >= 20 && l32 < 28)) && info_byte(o0, o1, own_idx) == 0;
         /* level strips (8 dwords + 1 of padding per lane) live in the team's still unused bit-string buffer */
-        uint32_t *strip = &s_mb[team][0] + l32 * 9;
+        lds_u32 *strip = (lds_u32 *)(&s_mb[team][0] + l32 * 9);
         uint32_t nz = 0;
         if (!empty) {
             const int16_t *src = B.levels + ((size_t)item * g.nmb + mb) * VENC_MB_COEFS + slot * 16;
@@ -557,46 +564,31 @@ __global__ __launch_bounds__(256) void k_cavlc(venc_geom g, venc_bufs B, venc_st
     if (valid) {
         uint32_t *dst = B.mbbits + ((size_t)item * g.nmb + mb) * VENC_MB_WORDS;
         for (int j = l32; j < nw; j += 32) dst[j] = s_mb[team][j];
-        /* one string for the whole macroblock = unit 0 of the region (the other units are empty) */
-        if (l32 == 0) *(uint4 *)(B.ubits + ((size_t)item * g.nmb + mb) * 8) = make_uint4((uint32_t)total, 0u, 0u, 0u);
+        if (l32 == 0) B.mbnbits[(size_t)item * g.nmb + mb] = (uint32_t)total;
     }
 }
 
 /* ================================================================== k_scan
- * One block per slice and item: exclusive scan of the macroblocks' bit counts (unit lengths -> running ends inside
- * the macroblock, macroblock offsets inside the slice); the block that finishes last for an item writes the item's
- * slice table (byte offsets inside the frame's output buffer).  The waves of a block take contiguous runs of the
+ * I pictures (P pictures need no scan kernel: venc_cavlc_p.hip).  One block per slice and item: exclusive scan of the
+ * macroblocks' bit counts (k_cavlc's mbnbits -> mboff, the offsets inside the slice); the block that finishes last for an item
+ * writes the item's slice table (byte offsets inside the frame's output buffer).  The waves of a block take contiguous runs of the
  * slice: a pass for the runs' totals, a block-wide exclusive sum of them, a second pass that scans and writes.
  * (The first version was one block per item with one wave per slice: 10 blocks per launch, 18 us at 1080p and
  * 60 us at 2160p, all of it latency, on a chain that had become nearly as long as the main chain.) */
-DEVFN uint32_t scan_unit_ends(const uint4 &u, uint4 &e) { /* lengths (l0 | l1 << 16, ...) -> running ends; returns the total */
-    e.x = u.x + (u.x << 16);
-    const uint32_t t1 = e.x >> 16;
-    e.y = u.y + (u.y << 16) + t1 * 0x00010001u;
-    const uint32_t t2 = e.y >> 16;
-    e.z = u.z + (u.z << 16) + t2 * 0x00010001u;
-    const uint32_t t3 = e.z >> 16;
-    e.w = u.w + (u.w << 16) + t3 * 0x00010001u;
-    return e.w >> 16;
-}
 #define SCAN_WAVES 16 /* (4 waves per block measured the same within noise: 143.8 against 145.3 Gpx/s at 1080p) */
 __global__ __launch_bounds__(64 * SCAN_WAVES) void k_scan(venc_geom g, venc_bufs B, venc_step S, venc_slice_out *slice_dev) {
     __shared__ uint32_t s_tot[SCAN_WAVES];
     __shared__ uint32_t s_last;
     const int item = blockIdx.y, s = S.slice0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    uint4 *ub = (uint4 *)(B.ubits + (size_t)item * g.nmb * 8); /* per macroblock: 8 x u16 unit lengths -> running ends */
-    uint32_t *nbp = B.mbnbits + (size_t)item * g.nmb;
+    const uint32_t *nbp = B.mbnbits + (size_t)item * g.nmb;
     uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
     const int per = ((last - first + SCAN_WAVES * 64 - 1) / (SCAN_WAVES * 64)) * 64; /* macroblocks per wave: whole groups of 64 */
     const int w0 = first + wv * per, w1 = min(w0 + per, last);
     /* pass 1: this wave's total */
     uint32_t acc = 0;
-#pragma unroll 1 /* registers: 16 waves of this block must fit beside two blocks of the motion search (<= 48 VGPRs) */
-    for (int i = w0 + lane; i < w1; i += 64) {
-        uint4 e;
-        acc += scan_unit_ends(ub[i], e);
-    }
+#pragma unroll 1
+    for (int i = w0 + lane; i < w1; i += 64) acc += nbp[i];
     const uint32_t wsum = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(acc), 63);
     if (lane == 0) s_tot[wv] = wsum;
     __syncthreads();
@@ -607,18 +599,13 @@ __global__ __launch_bounds__(64 * SCAN_WAVES) void k_scan(venc_geom g, venc_bufs
         running += k < wv ? t : 0u;
         total += t;
     }
-    /* pass 2: scan and write (the unit lengths come out of L2 this time) */
+    /* pass 2: scan and write (the lengths come out of L2 this time) */
 #pragma unroll 1
     for (int c0 = w0; c0 < w1; c0 += 64) {
         const int i = c0 + lane;
-        uint4 e = make_uint4(0, 0, 0, 0);
-        const uint32_t v = i < w1 ? scan_unit_ends(ub[i], e) : 0u;
+        const uint32_t v = i < w1 ? nbp[i] : 0u;
         const uint32_t incl = wave_scan_incl(v);
-        if (i < w1) {
-            ub[i] = e;
-            nbp[i] = v;
-            offp[i] = running + incl - v;
-        }
+        if (i < w1) offp[i] = running + incl - v;
         running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     /* slice total -> memory; the last block of the item to get here builds the slice table */
@@ -660,37 +647,30 @@ DEVFN uint32_t fetch_bits(const uint32_t *wds, int pos, int n) { /* 1 <= n <= 32
 }
 
 #define PACK_MBS 256
-/* running end k (0..7) of a macroblock's units, from its 8 x u16 vector */
-DEVFN uint32_t unit_end(const uint4 &e, int k) {
-    const uint32_t w = k < 2 ? e.x : k < 4 ? e.y : k < 6 ? e.z : e.w;
-    return (k & 1) ? w >> 16 : w & 0xffffu;
-}
-/* One block per run of up to 256 consecutive macroblocks of a slice; consecutive lanes build
- * consecutive output words (coalesced stores towards the pinned host buffer).  The bit offsets of
- * the run and the unit ends of its macroblocks sit in LDS; a word finds its first macroblock by binary
- * search there, the unit inside it by comparing against the seven ends (empty units vanish: their end
- * equals their start). */
+/* I pictures (P pictures: k_pack_p, venc_cavlc_p.hip).  One block per run of up to 256 consecutive macroblocks of a slice; consecutive
+ * lanes build consecutive output words (coalesced stores).  The bit offsets and lengths of the run sit in LDS; a word finds its
+ * first macroblock by binary search there. */
 __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_step S, const venc_slice_out *slice_dev) {
     __shared__ uint32_t s_off[PACK_MBS];
-    __shared__ uint4 s_end[PACK_MBS];
+    __shared__ uint32_t s_len[PACK_MBS];
     const int item = blockIdx.z, s = S.slice0 + blockIdx.y, tid = threadIdx.x;
     const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
     const int m0 = first + blockIdx.x * PACK_MBS;
     if (m0 >= last) return;
     const int n_here = min(PACK_MBS, last - m0);
     const venc_slice_out so = slice_dev[(size_t)item * g.n_slices + s];
-    const uint4 *endp = (const uint4 *)(B.ubits + (size_t)item * g.nmb * 8);
+    const uint32_t *lenp = B.mbnbits + (size_t)item * g.nmb;
     const uint32_t *offp = B.mboff + (size_t)item * g.nmb;
     const uint32_t *bits = B.mbbits + (size_t)item * g.nmb * VENC_MB_WORDS;
     uint32_t *out = (uint32_t *)(B.out_data + (size_t)S.out_slot[item] * B.out_data_stride + so.byte_off);
     if (tid < n_here) {
         s_off[tid] = offp[m0 + tid];
-        s_end[tid] = endp[m0 + tid];
+        s_len[tid] = lenp[m0 + tid];
     }
     __syncthreads();
     const uint32_t T = so.nbits;
     const uint32_t begin = s_off[0];
-    const uint32_t end = (m0 + n_here == last) ? so.nbytes * 8u : s_off[n_here - 1] + (s_end[n_here - 1].w >> 16);
+    const uint32_t end = (m0 + n_here == last) ? so.nbytes * 8u : s_off[n_here - 1] + s_len[n_here - 1];
     for (uint32_t w = ((begin + 31u) >> 5) + (uint32_t)tid; 32u * w < end; w += 256u) {
         if (so.byte_off + 4u * (w + 1u) > B.out_cap) break;
         uint32_t pos = 32u * w, val = 0;
@@ -704,24 +684,19 @@ __global__ __launch_bounds__(256) void k_pack(venc_geom g, venc_bufs B, venc_ste
         }
         int got = 0, m = lo;
         while (got < 32 && m0 + m < last) {
-            uint32_t mo;
-            uint4 e;
+            uint32_t mo, ml;
             if (m < n_here)
-                mo = s_off[m], e = s_end[m];
+                mo = s_off[m], ml = s_len[m];
             else
-                mo = offp[m0 + m], e = endp[m0 + m]; /* the word runs on into the next block's macroblocks */
+                mo = offp[m0 + m], ml = lenp[m0 + m]; /* the word runs on into the next block's macroblocks */
             const uint32_t local = pos - mo;
-            if (local >= (e.w >> 16)) { /* past this macroblock's last bit */
+            if (local >= ml) { /* past this macroblock's last bit */
                 m++;
                 continue;
             }
-            int u = 0; /* unit that holds bit `local`: the first whose end lies beyond it */
-#pragma unroll
-            for (int k = 0; k < 7; k++) u += (int)(unit_end(e, k) <= local);
-            const uint32_t ustart = u ? unit_end(e, u - 1) : 0u;
-            uint32_t take = unit_end(e, u) - local;
+            uint32_t take = ml - local;
             if (take > (uint32_t)(32 - got)) take = (uint32_t)(32 - got);
-            const uint32_t v = fetch_bits(bits + (size_t)(m0 + m) * VENC_MB_WORDS + u * VENC_UNIT_WORDS, (int)(local - ustart), (int)take);
+            const uint32_t v = fetch_bits(bits + (size_t)(m0 + m) * VENC_MB_WORDS, (int)local, (int)take);
             val = take == 32 ? v : ((val << take) | v);
             got += (int)take;
             pos += take;
