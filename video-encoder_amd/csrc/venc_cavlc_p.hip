@@ -1,12 +1,13 @@
 /*
- * venc_cavlc_p.hip -- entropy coding of P pictures, ONE LANE PER SYNTAX ENTRY.
+ * venc_cavlc_p.hip -- entropy coding of P pictures on SYNTAX ENTRIES.
  *
  * An ENTRY is the smallest piece of a P macroblock's syntax that can be coded on its own, because every CAVLC context (nC)
  * comes from the TotalCoeff values the transform kernels already stored, not from coded bits:
- *   slot 0        the macroblock header: slice header (first macroblock of a slice), mb_skip_run, mb_type, mvd_l0,
- *                 coded_block_pattern, mb_qp_delta -- or, for a skipped macroblock that ends its slice, the last mb_skip_run
- *   slot 1 .. 16  luma 4x4 block luma4x4BlkIdx = slot - 1 (present iff its 8x8 block's coded_block_pattern bit is set)
- *   slot 17, 18   Cb, Cr DC                 slot 19 .. 26  Cb, Cr AC blocks
+ *   slot 0        R: slice header (first macroblock of a slice) and mb_skip_run -- for a skipped macroblock that ends its slice
+ *                 the slice's last mb_skip_run
+ *   slot 1        H: mb_type, mvd_l0, coded_block_pattern, mb_qp_delta of a coded macroblock
+ *   slot 2 .. 17  luma 4x4 block luma4x4BlkIdx = slot - 2 (present iff its 8x8 block's coded_block_pattern bit is set)
+ *   slot 18, 19   Cb, Cr DC                 slot 20 .. 27  Cb, Cr AC blocks
  * Slots are numbered in bitstream order, so the entries of a slice sorted by (macroblock, slot) ARE its slice_data().
  *
  * History.  Round 1 gave a macroblock to one lane (a wave lasted as long as its heaviest macroblock, ~100 us), then eight
@@ -17,209 +18,255 @@
  * macroblock, k_scan turned eight unit lengths per macroblock into offsets and k_pack read ONE 128-BYTE LINE PER UNIT to collect
  * a few words: 98 MB read to write 1.5 MB (profiles/pmc_traffic.json of round 3).
  *
- * Round 4 (this file):
- *   k_skip2     one lane per macroblock, blocks of 256 macroblocks OF ONE SLICE ("segments"): P_Skip decision, the mask of
- *               coded macroblocks (slice-relative words), and the segment's entries in bitstream order -- a block scan, no atomic
- *   k_cavlc_p2  one lane per entry of a segment: the entry's bit string leaves as ONE 16-byte store (venc_bitsink4: four words
- *               in registers; the rare entry beyond 128 bits spills into the macroblock's region of mbbits), its bit offset
- *               inside the segment comes from a block scan of the lengths, the segment's total goes to seg_bits
- *   k_pack_p    one block per segment: every block sums the picture's segment totals itself (a few dozen numbers: no scan kernel),
- *               ORs its entries into an LDS window at their bit offsets and streams the window out; the block of a picture's
- *               first segment also writes the slice table
- * A lane's work is one header or ONE 4x4 block (most of them a coeff_token and a level or two), the gather reads 20 bytes per
- * entry from dense arrays, and k_scan has left the P chain.  I pictures (26 dense blocks in every macroblock) stay on k_cavlc /
- * k_scan / k_pack (venc_kernels.hip).
+ * Round 4 (this file), three kernels, each one block per SEGMENT = 256 macroblocks of one slice:
+ *   k_skip2     one lane per macroblock, which holds its own, its left and its upper record: P_Skip decision, the mask of coded
+ *               macroblocks (slice-relative words), the nC of all 24 blocks at once (packed bytes), and the macroblock's entries
+ *               in bitstream order -- a block scan, no atomic.  What needs nothing else is FINISHED here: the H entry and the
+ *               coeff_token of every block without a level (most entries: a coded 8x8 block holds one or two blocks with
+ *               levels); R entries and blocks with levels are listed for k_cavlc_p2 with their nC
+ *   k_cavlc_p2  one lane per listed entry: mb_skip_run from the mask / one residual block from its 32 bytes of levels.  An
+ *               entry's string leaves as ONE 16-byte store (venc_bitsink4: four words in registers; the rare entry beyond
+ *               128 bits spills into the macroblock's region of mbbits); the block ends with an exclusive scan of all the
+ *               segment's lengths = the entries' bit offsets
+ *   k_pack_p    every block sums the picture's segment totals itself (a few dozen numbers: no scan kernel), ORs its entries
+ *               into an LDS window at their bit offsets and streams the window out; the block of a picture's first segment
+ *               also writes the slice table
+ * The first form of this round gave every entry a lane of one mixed kernel: 14.0 M vector instructions per batch of four
+ * 1080p steps (half a motion search) -- a wave walked the header path AND the longest block of its 64 entries for what was
+ * mostly one-bit tokens.  I pictures (26 dense blocks in every macroblock) stay on k_cavlc / k_scan / k_pack (venc_kernels.hip).
  */
 
 #define ENT_SEG_MBS 256   /* macroblocks of one slice per segment */
-#define ENT_PER_MB 27     /* entries a macroblock can have */
+#define ENT_PER_MB 28     /* entries a macroblock can have */
 #define ENT_THREADS 256
 
-/* segment index of (pair v, slice s, segment j of the slice) and the geometry that goes with it */
+/* segment index of (pair v, slice s, segment j of the slice) */
 DEVFN size_t ent_seg(const venc_geom &g, const venc_bufs &B, int v, int s, int j) { return ((size_t)v * g.n_slices + s) * B.ent_spp + j; }
+/* record slot of an entry's levels (27 per macroblock: luma 0 .. 15, Intra16x16 DC, Cb / Cr DC, Cb / Cr AC) */
+DEVFN int ent_level_slot(int slot) { return slot < 18 ? slot - 2 : slot - 1; }
 
-/* ================================================================== k_skip2
- * grid = (segments per slice, slices of the band, (step, item) pairs).  P_Skip (7.3.4): no residual and the vector a decoder
- * infers (mb_is_p_skip).  The coded-macroblock mask is a wave ballot per 64 macroblocks OF THE SLICE; k_cavlc_p2 derives
- * mb_skip_run from it by looking backwards for the previous coded macroblock -- a count-leading-zeros per word, and whole rows of
- * skipped macroblocks are a handful of words.
- * The segment's entries are listed twice: in bitstream order (ent_list[rank] = mb << 5 | slot: what rank means downstream) and
- * SORTED BY KIND for the coder (ent_cls: headers | blocks with a level | blocks without; element = rank << 13 | macroblock of the
- * segment << 5 | slot), so that a wave of k_cavlc_p2 holds one kind of work.  Unsorted (first form of this round) a wave walked the
- * header path AND the longest block of its 64 entries for what was mostly one-bit tokens of empty blocks: 14.0 M vector
- * instructions per batch of four 1080p steps, half a motion search. */
 DEVFN uint32_t nonzero_bytes4(uint32_t w) { /* bit k = byte k of w is not zero */
     return (uint32_t)((w & 0xffu) != 0u) | ((uint32_t)((w & 0xff00u) != 0u) << 1) | ((uint32_t)((w & 0xff0000u) != 0u) << 2) | ((uint32_t)((w >> 24) != 0u) << 3);
 }
-__global__ __launch_bounds__(ENT_SEG_MBS) void k_skip2(venc_geom g, venc_bufs B, venc_step S) {
-    __shared__ uint32_t s_wa[ENT_SEG_MBS / 64], s_wh[ENT_SEG_MBS / 64];
-    const int v = blockIdx.z, s = S.slice0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+/* nC (9.2.1) of four blocks at once: A / B = the TotalCoeff of their left / upper neighbours, one per byte (<= 16), mA / mB =
+ * 0xff where that neighbour is available: (A + B + 1) >> 1 with both, the one that is there, or 0 */
+DEVFN uint32_t nc_bytes4(uint32_t A, uint32_t Bv, uint32_t mA, uint32_t mB) {
+    const uint32_t both = ((A + Bv + 0x01010101u) >> 1) & 0x7f7f7f7fu;
+    return (both & mA & mB) | (A & mA & ~mB) | (Bv & ~mA & mB);
+}
+
+/* ================================================================== k_entropy_p
+ * grid = (segments per slice, slices of the band, (step, item) pairs); block = 256 lanes = the segment's macroblocks.
+ *
+ * PHASE A, one lane per macroblock, which holds its own, its left and its upper record.  P_Skip (7.3.4: no residual and the
+ * vector a decoder infers, 8.4.1.1); the coded-macroblock mask as wave ballots (LDS); nC of the macroblock's 24 blocks at once
+ * (packed bytes); its entries in bitstream order, their ranks from ONE block scan (no atomic).  Entries that need nothing else
+ * are FINISHED here -- H, and the coeff_token of every block without a level (most entries: a coded 8x8 block holds one or two
+ * blocks with levels) -- the others (R, blocks with levels) are listed in LDS with their nC.  Meanwhile the first wave looks
+ * BACKWARDS from the segment's start for the last coded macroblock before it (64 macroblocks per step, nearly always one step):
+ * the only thing a segment needs from its predecessors, and what lets one launch do what k_skip + k_cavlc_p did in two.
+ * PHASE B, one lane per listed entry: mb_skip_run from the mask / one residual block from its 32 bytes of levels.
+ * PHASE C: exclusive scan of all lengths (LDS) = the entries' bit offsets inside the segment.
+ * An entry's string leaves as ONE 16-byte store (venc_bitsink4: four words in registers; the rare entry beyond 128 bits spills
+ * into the macroblock's region of mbbits and says so in ent_list).
+ * Dynamic LDS: 36 bytes per lane (the 16 levels of the block being coded + a dword against bank conflicts), 2 bytes per entry
+ * the segment can hold (lengths), 4 bytes x ENT_CLS_LDS (the list of phase B; longer lists continue in memory). */
+#define ENT_CLS_LDS 2048
+__global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_bufs B, venc_step S) {
+    extern __shared__ uint32_t s_dyn[];
+    __shared__ uint16_t s_tab[VENC_TAB_SIZE];
+    __shared__ uint32_t s_wa[ENT_THREADS / 64], s_wr[ENT_THREADS / 64], s_wtot[2][ENT_THREADS / 64];
+    __shared__ unsigned long long s_mask[ENT_SEG_MBS / 64];
+    __shared__ uint32_t s_prev_run;
+    const int v = blockIdx.z, s = S.slice0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int srow = B.slice_first_row[s];
     const int first = srow * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
     if (j * ENT_SEG_MBS >= last - first) return;
-    const int rel = j * ENT_SEG_MBS + tid, mb = first + rel;
+    lds_u32 *strip = (lds_u32 *)(s_dyn + tid * 9); /* (written as dwords, read by the coder as int16: may_alias, see venc_kernels.hip) */
+    uint16_t *s_len = (uint16_t *)(s_dyn + ENT_THREADS * 9);
+    uint32_t *s_cls = s_dyn + ENT_THREADS * 9 + ((B.ent_cap + 7u) >> 3) * 4u; /* (behind the lengths, 16-byte aligned) */
+    const int mb_seg = first + j * ENT_SEG_MBS;
+    const int mb = mb_seg + tid;
     const bool in = mb < last;
     const int mbc = in ? mb : first;
     const int my = mbc / g.mbw, mx = mbc - my * g.mbw;
-    const uint4 *ip = (const uint4 *)(B.mbinfo + (size_t)v * g.nmb + mbc); /* the whole record: nnz[24], cbp, flags, cbpc */
-    const uint4 o0 = ip[0], o1 = ip[1];
-    const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u);
-    const bool skip = in && mb_is_p_skip(g, B.mvsad + (size_t)v * g.nmb, mbc, mx, mx > 0, my > srow, cbpl | (cbpc << 4));
-    const unsigned long long coded = __ballot(in && !skip);
-    if ((tid & 63) == 0) B.codedmask[((size_t)v * g.n_slices + s) * B.ent_wps + (rel >> 6)] = coded;
-    uint32_t em = 0, nm = 0; /* bit = slot: entries; those that are blocks with a level (the chroma DC blocks count as such: their record has no count) */
-    if (in) {
-        if (skip)
-            em = (mb == last - 1 || rel == 0) ? 1u : 0u; /* the slice's last mb_skip_run / its header */
-        else {
-            em = 1u;
-#pragma unroll
-            for (int q = 0; q < 4; q++) em |= ((cbpl >> q) & 1) ? 0xfu << (1 + 4 * q) : 0u;
-            em |= cbpc > 0 ? 3u << 17 : 0u;
-            em |= cbpc == 2 ? 0xffu << 19 : 0u;
-            const uint32_t nzr = nonzero_bytes4(o0.x) | (nonzero_bytes4(o0.y) << 4) | (nonzero_bytes4(o0.z) << 8) | (nonzero_bytes4(o0.w) << 12); /* luma, raster order */
-#pragma unroll
-            for (int bk = 0; bk < 16; bk++) nm |= ((nzr >> (blk_y(bk) * 4 + blk_x(bk))) & 1u) << (1 + bk);
-            nm |= 3u << 17;
-            nm |= (nonzero_bytes4(o1.x) | (nonzero_bytes4(o1.y) << 4)) << 19;
-            nm &= em;
-        }
-    }
-    const uint32_t n_all = (uint32_t)__popc(em), n_n = (uint32_t)__popc(nm), n_h = em & 1u;
-    const uint32_t ia = wave_scan_incl(n_all | (n_n << 16)), ih = wave_scan_incl(n_h);
-    if ((tid & 63) == 63) s_wa[tid >> 6] = ia, s_wh[tid >> 6] = ih;
-    __syncthreads();
-    uint32_t xa = ia - (n_all | (n_n << 16)), xh = ih - n_h, ta = 0, th = 0;
-#pragma unroll
-    for (int k = 0; k < ENT_SEG_MBS / 64; k++) {
-        const uint32_t a = s_wa[k], h = s_wh[k];
-        xa += k < (tid >> 6) ? a : 0u;
-        xh += k < (tid >> 6) ? h : 0u;
-        ta += a;
-        th += h;
-    }
-    const uint32_t total = ta & 0xffffu, tot_n = ta >> 16;
-    uint32_t rank = xa & 0xffffu, pos_n = th + (xa >> 16), pos_h = xh, pos_e = th + tot_n + (rank - xh - (xa >> 16));
-    const size_t seg = ent_seg(g, B, v, s, j);
-    uint32_t *list = B.ent_list + seg * B.ent_cap, *cls = B.ent_cls + seg * B.ent_cap;
-    while (em) {
-        const int slot = __builtin_ctz(em);
-        em &= em - 1u;
-        const uint32_t rec = (rank << 13) | ((uint32_t)tid << 5) | (uint32_t)slot;
-        list[rank++] = ((uint32_t)mb << 5) | (uint32_t)slot;
-        if (slot == 0)
-            cls[pos_h++] = rec;
-        else if ((nm >> slot) & 1u)
-            cls[pos_n++] = rec;
-        else
-            cls[pos_e++] = rec;
-    }
-    if (tid == 0) *(uint4 *)(B.ent_count + 4 * seg) = make_uint4(total, th, tot_n, 0u);
-}
-
-/* P_Skip macroblocks directly before the macroblock at slice-relative index rel, from the slice's coded-macroblock mask */
-DEVFN uint32_t skip_run_before(const unsigned long long *mask, int rel) {
-    int w = rel >> 6;
-    unsigned long long m = mask[w] & ((1ull << (rel & 63)) - 1ull); /* coded macroblocks below rel in its word */
-    for (;;) {
-        if (m) return (uint32_t)(rel - 1 - ((w << 6) + 63 - __builtin_clzll(m)));
-        if (w == 0) return (uint32_t)rel;
-        w--;
-        m = mask[w];
-    }
-}
-
-/* a residual block's place in the records: level slot, scan range, the counts of its left / upper neighbours -> nC (9.2.1) */
-DEVFN int ent_block_nc(const venc_geom &g, const venc_mbinfo *infos, int mb, int lslot, bool aL, bool aT, int &firstc, int &maxc) {
-    firstc = 0, maxc = 16;
-    if (lslot == 17 || lslot == 18) {
-        maxc = 4;
-        return -1;
-    }
-    int ia, ib;
-    bool inA, inB;
-    if (lslot < 16) {
-        const int bx = blk_x(lslot), by = blk_y(lslot);
-        inA = bx > 0, inB = by > 0;
-        ia = inA ? by * 4 + bx - 1 : by * 4 + 3;
-        ib = inB ? (by - 1) * 4 + bx : 12 + bx;
-    } else {
-        firstc = 1, maxc = 15;
-        const int kk = (lslot - 19) & 3, nb = 16 + 4 * ((lslot - 19) >> 2);
-        const int bx = kk & 1, by = kk >> 1;
-        inA = bx > 0, inB = by > 0;
-        ia = inA ? nb + 2 * by : nb + 2 * by + 1;
-        ib = inB ? nb + bx : nb + 2 + bx;
-    }
-    const bool haveA = inA || aL, haveB = inB || aT;
-    const int nA = haveA ? (int)infos[inA ? mb : mb - 1].nnz[ia] : 0;
-    const int nB = haveB ? (int)infos[inB ? mb : mb - g.mbw].nnz[ib] : 0;
-    return venc_nc(haveA, nA, haveB, nB);
-}
-
-/* ================================================================== k_cavlc_p2
- * grid as k_skip2; the waves of a block walk the segment's headers, then its blocks with a level, then its empty blocks (no
- * barrier between them), leave every entry's string at head[rank] and its length in LDS, and the block ends with an exclusive scan
- * of the lengths in rank order.  Dynamic LDS: 36 bytes per lane (the 16 levels of the block being coded + a dword against bank
- * conflicts), then 2 bytes per entry the segment can hold. */
-__global__ __launch_bounds__(ENT_THREADS) void k_cavlc_p2(venc_geom g, venc_bufs B, venc_step S) {
-    extern __shared__ uint32_t s_dyn[];
-    __shared__ uint16_t s_tab[VENC_TAB_SIZE];
-    __shared__ uint32_t s_wtot[2][ENT_THREADS / 64];
-    const int v = blockIdx.z, s = S.slice0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
-    const int srow = B.slice_first_row[s];
-    const int first = srow * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
-    if (j * ENT_SEG_MBS >= last - first) return;
-    const size_t seg = ent_seg(g, B, v, s, j);
-    const uint4 cc = *(const uint4 *)(B.ent_count + 4 * seg);
-    const uint32_t count = min(cc.x, B.ent_cap), n_h = min(cc.y, count), n_hn = min(cc.y + cc.z, count);
-    const uint32_t *cls = B.ent_cls + seg * B.ent_cap;
-    uint4 *head = B.ent_head + seg * B.ent_cap;
-    uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
-    lds_u32 *strip = (lds_u32 *)(s_dyn + tid * 9); /* (written as dwords, read by the coder as int16: may_alias, see venc_kernels.hip) */
-    uint16_t *s_len = (uint16_t *)(s_dyn + ENT_THREADS * 9);
-    for (int i = tid; i < VENC_TAB_SIZE; i += ENT_THREADS) {
+    const bool aL = mx > 0, aT = my > srow;
+    const venc_mbinfo *infos = B.mbinfo + (size_t)v * g.nmb;
+    const uint32_t *mvs = B.mvsad + (size_t)v * g.nmb;
+    /* ---------------------------------------------------------------- phase A */
+    const uint4 *ip = (const uint4 *)(infos + mbc), *lp = (const uint4 *)(infos + (aL ? mbc - 1 : mbc)), *tp = (const uint4 *)(infos + (aT ? mbc - g.mbw : mbc));
+    const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
+    const uint32_t me = mvs[mbc];
+    int pxv, pyv;
+    bool zero_inferred;
+    mv_predict(g, mvs, mbc, mx, aL, aT, pxv, pyv, zero_inferred);
+    for (int i = tid; i < VENC_TAB_SIZE; i += ENT_THREADS) { /* (the VLC tables of phase B: their loads fly with the records') */
         s_tab[i] = i < VENC_TAB_TOKEN_CDC  ? venc_vlc_coeff_token[i]
                  : i < VENC_TAB_TZ         ? venc_vlc_coeff_token_cdc[i - VENC_TAB_TOKEN_CDC]
                  : i < VENC_TAB_TZ_CDC     ? venc_vlc_total_zeros[i - VENC_TAB_TZ]
                  : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                            : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
-    __syncthreads();
-    const venc_mbinfo *infos = B.mbinfo + (size_t)v * g.nmb;
-    const unsigned long long *mask = B.codedmask + ((size_t)v * g.n_slices + s) * B.ent_wps;
-    const int mb_seg = first + j * ENT_SEG_MBS;
-    /* ---- headers */
-    for (uint32_t k = tid; k < n_h; k += ENT_THREADS) {
-        const uint32_t e = cls[k], rank = e >> 13;
-        const int mb = mb_seg + (int)((e >> 5) & 255u);
-        const int my = mb / g.mbw, mx = mb - my * g.mbw;
-        venc_bitsink4 bs;
-        venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mb) * VENC_MB_WORDS);
-        const uint32_t rec = ((const uint32_t *)(infos + mb))[6];
-        const int cbp = (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4);
-        const int rel = mb - first;
-        const bool skipped = !((mask[rel >> 6] >> (rel & 63)) & 1ull);
-        if (rel == 0) emit_slice_header(&bs, mb, S, v, B);
-        if (!skipped || mb == last - 1) {
-            const uint32_t run = skip_run_before(mask, rel);
-            if (skipped)
-                venc_bs_ue(&bs, run + 1u); /* a slice that ends in skipped macroblocks carries their count as a last mb_skip_run */
-            else
-                emit_p_mb_header(&bs, g, B.mvsad + (size_t)v * g.nmb, mb, mx, my, mx > 0, my > srow, cbp, run);
+    const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+    const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
+    const bool skip = in && cbp == 0 && (zero_inferred ? (dx == 0 && dy == 0) : (dx == pxv && dy == pyv));
+    const unsigned long long coded = __ballot(in && !skip);
+    if (lane == 0) s_mask[tid >> 6] = coded;
+    uint32_t em = 0, nm = 0; /* bit = slot: entries; those that are blocks with a level (the chroma DC blocks count as such: their record has no count) */
+    if (in) {
+        if (skip)
+            em = (mb == last - 1 || mb == first) ? 1u : 0u; /* the slice's last mb_skip_run / its header */
+        else {
+            em = 3u;
+#pragma unroll
+            for (int q = 0; q < 4; q++) em |= ((cbpl >> q) & 1) ? 0xfu << (2 + 4 * q) : 0u;
+            em |= cbpc > 0 ? 3u << 18 : 0u;
+            em |= cbpc == 2 ? 0xffu << 20 : 0u;
+            const uint32_t nzr = nonzero_bytes4(o0.x) | (nonzero_bytes4(o0.y) << 4) | (nonzero_bytes4(o0.z) << 8) | (nonzero_bytes4(o0.w) << 12); /* luma, raster order */
+#pragma unroll
+            for (int bk = 0; bk < 16; bk++) nm |= ((nzr >> (blk_y(bk) * 4 + blk_x(bk))) & 1u) << (2 + bk);
+            nm |= 3u << 18;
+            nm |= (nonzero_bytes4(o1.x) | (nonzero_bytes4(o1.y) << 4)) << 20;
+            nm &= em;
         }
-        s_len[rank] = (uint16_t)venc_bs_flush(&bs);
-        head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
     }
-    /* ---- blocks that hold a level (and the chroma DC blocks) */
-    for (uint32_t k = n_h + tid; k < n_hn; k += ENT_THREADS) {
-        const uint32_t e = cls[k], rank = e >> 13;
-        const int slot = (int)(e & 31u), mb = mb_seg + (int)((e >> 5) & 255u);
-        const int my = mb / g.mbw, mx = mb - my * g.mbw;
-        const int lslot = slot <= 16 ? slot - 1 : slot;
-        int firstc, maxc;
-        const int nC = ent_block_nc(g, infos, mb, lslot, mx > 0, my > srow, firstc, maxc);
-        const int16_t *lv = B.levels + ((size_t)v * g.nmb + mb) * VENC_MB_COEFS + lslot * 16;
+    /* ranks (bitstream order) and the places in phase B's list: one block scan of three counts */
+    const uint32_t n_all = (uint32_t)__popc(em), n_n = (uint32_t)__popc(nm), n_r = em & 1u;
+    const uint32_t ia = wave_scan_incl(n_all | (n_n << 16)), ir = wave_scan_incl(n_r);
+    if (lane == 63) s_wa[tid >> 6] = ia, s_wr[tid >> 6] = ir;
+    /* the first wave: P_Skip macroblocks directly before the segment (the run a mb_skip_run of this segment may continue) */
+    if (tid < 64) {
+        uint32_t prev = 0;
+        if (j > 0) {
+            int base = mb_seg;
+            for (;;) {
+                const int idx = base - 1 - lane;
+                const bool valid = idx >= first;
+                const int ic = valid ? idx : first;
+                const int iy = ic / g.mbw, ix = ic - iy * g.mbw;
+                const uint32_t rec = ((const uint32_t *)(infos + ic))[6];
+                const bool sk = mb_is_p_skip(g, mvs, ic, ix, ix > 0, iy > srow, (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4));
+                const unsigned long long cb = __ballot(valid && !sk), vb = __ballot(valid);
+                if (cb) {
+                    prev += (uint32_t)__builtin_ctzll(cb);
+                    break;
+                }
+                prev += (uint32_t)__popcll(vb);
+                if (vb != ~0ull) break; /* the slice's start */
+                base -= 64;
+            }
+        }
+        if (lane == 0) s_prev_run = prev;
+    }
+    __syncthreads();
+    uint32_t xa = ia - (n_all | (n_n << 16)), xr = ir - n_r, ta = 0, tr = 0;
+#pragma unroll
+    for (int k = 0; k < ENT_THREADS / 64; k++) {
+        const uint32_t a = s_wa[k], r = s_wr[k];
+        xa += k < (tid >> 6) ? a : 0u;
+        xr += k < (tid >> 6) ? r : 0u;
+        ta += a;
+        tr += r;
+    }
+    const size_t seg = ent_seg(g, B, v, s, j);
+    const uint32_t count = ta & 0xffffu, n_r_all = tr, n_rn = tr + (ta >> 16);
+    uint4 *head = B.ent_head + seg * B.ent_cap;
+    uint32_t *cls_mem = B.ent_cls + seg * B.ent_cap, *list = B.ent_list + seg * B.ent_cap;
+    if (in) B.ent_mb0[(size_t)v * g.nmb + mb] = (xa & 0xffffu) | (n_all << 16); /* (debug / tests: the macroblock's entries are ranks [lo, lo + hi)) */
+    if (em) {
+        uint32_t rank = xa & 0xffffu, pos_r = xr, pos_n = tr + (xa >> 16);
+        /* nC of the macroblock's 24 blocks: luma rows ncl[y] (byte = x), chroma planes ncc[plane] (byte = 2 y + x) */
+        uint32_t ncl[4], ncc[2];
+        {
+            const uint32_t mLa = aL ? 0xffffffffu : 0xffffff00u, mTa = aT ? 0xffffffffu : 0u;
+            const uint32_t own[4] = {o0.x, o0.y, o0.z, o0.w}, lft[4] = {l0.x, l0.y, l0.z, l0.w};
+#pragma unroll
+            for (int y = 0; y < 4; y++)
+                ncl[y] = nc_bytes4(__builtin_amdgcn_alignbyte(own[y], lft[y], 3u), y ? own[y - 1] : t0.w, mLa, y ? 0xffffffffu : mTa);
+            const uint32_t mLc = aL ? 0xffffffffu : 0xff00ff00u, mTc = aT ? 0xffffffffu : 0xffff0000u;
+            const uint32_t oc[2] = {o1.x, o1.y}, lc[2] = {l1.x, l1.y}, tc[2] = {t1.x, t1.y};
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+                ncc[pl] = nc_bytes4(__builtin_amdgcn_perm(oc[pl], lc[pl], 0x06030401u), __builtin_amdgcn_alignbyte(oc[pl], tc[pl], 2u), mLc, mTc);
+        }
+        while (em) {
+            const int slot = __builtin_ctz(em);
+            em &= em - 1u;
+            if (slot == 0) {
+                const uint32_t rec = (rank << 18) | ((uint32_t)tid << 5);
+                if (pos_r < ENT_CLS_LDS) s_cls[pos_r] = rec; else cls_mem[pos_r] = rec;
+                pos_r++;
+            } else if (slot == 1) {
+                /* mb_type P_L0_16x16, mvd_l0 in quarter samples, coded_block_pattern, mb_qp_delta: at most 49 bits */
+                venc_bitsink4 bs;
+                venc_bs4_init(&bs, nullptr);
+                venc_bs_ue(&bs, 0u);
+                venc_bs_se(&bs, (dx - pxv) << (g.subpel ? 0 : 2));
+                venc_bs_se(&bs, (dy - pyv) << (g.subpel ? 0 : 2));
+                venc_bs_ue(&bs, venc_cbp_inter_code[cbp]);
+                if (cbp) venc_bs_se(&bs, 0);
+                s_len[rank] = (uint16_t)venc_bs_flush(&bs);
+                head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
+            } else {
+                uint32_t nC;
+                if (slot < 18) {
+                    const int bk = slot - 2, by = blk_y(bk), bx = blk_x(bk);
+                    const uint32_t wd = by == 0 ? ncl[0] : by == 1 ? ncl[1] : by == 2 ? ncl[2] : ncl[3];
+                    nC = (wd >> (8 * bx)) & 255u;
+                } else
+                    nC = slot < 20 ? 0u : ((slot < 24 ? ncc[0] : ncc[1]) >> (8 * ((slot - 20) & 3))) & 255u;
+                if ((nm >> slot) & 1u) {
+                    const uint32_t rec = (rank << 18) | ((slot == 18 || slot == 19 ? 0u : nC + 1u) << 13) | ((uint32_t)tid << 5) | (uint32_t)slot;
+                    if (pos_n < ENT_CLS_LDS) s_cls[pos_n] = rec; else cls_mem[pos_n] = rec;
+                    pos_n++;
+                } else { /* coeff_token of TotalCoeff 0 (table 9-5): 1, 11, 1111, 0000 11 for nC < 2, < 4, < 8, >= 8 */
+                    const uint32_t len = nC < 2u ? 1u : nC < 4u ? 2u : nC < 8u ? 4u : 6u;
+                    s_len[rank] = (uint16_t)len;
+                    head[rank] = make_uint4((nC < 8u ? 0xffffffffu : 0x0c000000u) << (nC < 8u ? 32u - len : 0u), 0u, 0u, 0u);
+                }
+            }
+            rank++;
+        }
+    }
+    __syncthreads();
+    /* ---------------------------------------------------------------- phase B */
+    /* R: slice header, mb_skip_run */
+    for (uint32_t k = tid; k < n_r_all; k += ENT_THREADS) {
+        const uint32_t e = k < ENT_CLS_LDS ? s_cls[k] : cls_mem[k], rank = e >> 18;
+        const int r = (int)((e >> 5) & 255u), mbk = mb_seg + r;
+        venc_bitsink4 bs;
+        venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mbk) * VENC_MB_WORDS);
+        const bool skipped = !((s_mask[r >> 6] >> (r & 63)) & 1ull);
+        if (mbk == first) emit_slice_header(&bs, mbk, S, v, B);
+        if (!skipped || mbk == last - 1) {
+            int w = r >> 6;
+            unsigned long long m = s_mask[w] & ((1ull << (r & 63)) - 1ull); /* coded macroblocks of the segment below r in its word */
+            uint32_t run;
+            for (;;) {
+                if (m) {
+                    run = (uint32_t)(r - 1 - ((w << 6) + 63 - __builtin_clzll(m)));
+                    break;
+                }
+                if (w == 0) {
+                    run = (uint32_t)r + s_prev_run;
+                    break;
+                }
+                w--;
+                m = s_mask[w];
+            }
+            venc_bs_ue(&bs, skipped ? run + 1u : run); /* (a slice that ends in skipped macroblocks carries their count as a last mb_skip_run) */
+        }
+        const int bits = venc_bs_flush(&bs);
+        s_len[rank] = (uint16_t)bits;
+        head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
+        if (bits > 128) list[rank] = (uint32_t)mbk << 5;
+    }
+    /* blocks that hold a level (and the chroma DC blocks) */
+    for (uint32_t k = n_r_all + tid; k < n_rn; k += ENT_THREADS) {
+        const uint32_t e = k < ENT_CLS_LDS ? s_cls[k] : cls_mem[k], rank = e >> 18;
+        const int slot = (int)(e & 31u), mbk = mb_seg + (int)((e >> 5) & 255u), nC = (int)((e >> 13) & 31u) - 1;
+        const int firstc = slot >= 20 ? 1 : 0, maxc = slot >= 20 ? 15 : slot >= 18 ? 4 : 16;
+        const int16_t *lv = B.levels + ((size_t)v * g.nmb + mbk) * VENC_MB_COEFS + ent_level_slot(slot) * 16;
         const uint4 a = ((const uint4 *)lv)[0];
         strip[0] = a.x, strip[1] = a.y, strip[2] = a.z, strip[3] = a.w;
         uint32_t wds[8] = {a.x, a.y, a.z, a.w, 0u, 0u, 0u, 0u};
@@ -236,32 +283,23 @@ __global__ __launch_bounds__(ENT_THREADS) void k_cavlc_p2(venc_geom g, venc_bufs
         }
         nz = (nz >> firstc) & ((1u << maxc) - 1u);
         venc_bitsink4 bs;
-        venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mb) * VENC_MB_WORDS + slot * VENC_LANE_WORDS);
+        venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mbk) * VENC_MB_WORDS + slot * VENC_LANE_WORDS);
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, firstc, maxc, nC, s_tab);
-        s_len[rank] = (uint16_t)venc_bs_flush(&bs);
+        const int bits = venc_bs_flush(&bs);
+        s_len[rank] = (uint16_t)bits;
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
-    }
-    /* ---- blocks without a level inside a coded 8x8 block / coded chroma AC: coeff_token of TotalCoeff 0 for their nC */
-    for (uint32_t k = n_hn + tid; k < count; k += ENT_THREADS) {
-        const uint32_t e = cls[k], rank = e >> 13;
-        const int slot = (int)(e & 31u), mb = mb_seg + (int)((e >> 5) & 255u);
-        const int my = mb / g.mbw, mx = mb - my * g.mbw;
-        int firstc, maxc;
-        const int nC = ent_block_nc(g, infos, mb, slot <= 16 ? slot - 1 : slot, mx > 0, my > srow, firstc, maxc);
-        const uint32_t tok = s_tab[VENC_TAB_TOKEN + (nC < 2 ? 0 : nC < 4 ? 68 : nC < 8 ? 136 : 204)];
-        const uint32_t len = tok >> 8;
-        s_len[rank] = (uint16_t)len;
-        head[rank] = make_uint4((tok & 0xffu) << (32u - len), 0u, 0u, 0u);
+        if (bits > 128) list[rank] = ((uint32_t)mbk << 5) | (uint32_t)slot;
     }
     __syncthreads();
-    /* ---- bit offsets inside the segment: exclusive scan of the lengths in rank order */
+    /* ---------------------------------------------------------------- phase C: bit offsets = exclusive scan of the lengths in rank order */
+    uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
     uint32_t base_bits = 0;
     int phase = 0;
     for (uint32_t k0 = 0; k0 < count; k0 += ENT_THREADS, phase ^= 1) {
         const uint32_t k = k0 + (uint32_t)tid;
         const uint32_t bits = k < count ? (uint32_t)s_len[k] : 0u;
         const uint32_t incl = wave_scan_incl(bits);
-        if ((tid & 63) == 63) s_wtot[phase][tid >> 6] = incl;
+        if (lane == 63) s_wtot[phase][tid >> 6] = incl;
         __syncthreads();
         uint32_t woff = 0, tot = 0;
 #pragma unroll
@@ -276,6 +314,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_cavlc_p2(venc_geom g, venc_bufs
     if (tid == 0) {
         off[count] = base_bits;
         B.seg_bits[seg] = base_bits;
+        B.ent_count[seg] = count;
     }
 }
 
@@ -347,7 +386,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_pack_p(venc_geom g, venc_bufs B
     __syncthreads();
     const uint32_t T = s_sl_bits[sb], nbytes = (T + 1 + 7) >> 3, byte_off = s_sl_off[s];
     const size_t seg = ent_seg(g, B, v, s, j);
-    const uint32_t count = min(B.ent_count[4 * seg], B.ent_cap);
+    const uint32_t count = min(B.ent_count[seg], B.ent_cap);
     const uint32_t *list = B.ent_list + seg * B.ent_cap;
     const uint4 *head = B.ent_head + seg * B.ent_cap;
     const uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
@@ -364,7 +403,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_pack_p(venc_geom g, venc_bufs B
         for (uint32_t k = tid; k < count; k += ENT_THREADS) {
             const uint32_t o = begin + off[k], len = off[k + 1] - off[k];
             if (len == 0 || o + len <= 32u * w0 || o >= 32u * w1) continue;
-            const uint32_t e = list[k];
+            const uint32_t e = len > 128u ? list[k] : 0u; /* (only a string beyond its four head words says where the rest lies) */
             ent_or_into(s_win, w0, w1, o, len, head[k], mbb + (size_t)(e >> 5) * VENC_MB_WORDS + (e & 31u) * VENC_LANE_WORDS);
         }
         /* the window's last word may run on into the following segments (never past the slice: the last segment ends it) */
@@ -372,13 +411,13 @@ __global__ __launch_bounds__(ENT_THREADS) void k_pack_p(venc_geom g, venc_bufs B
             uint32_t obase = seg_end;
             for (int jj = j + 1; jj < nseg && obase < 32u * w1; jj++) {
                 const size_t sg = ent_seg(g, B, v, s, jj);
-                const uint32_t cn = min(B.ent_count[4 * sg], B.ent_cap);
+                const uint32_t cn = min(B.ent_count[sg], B.ent_cap);
                 const uint32_t *of = B.ent_off + sg * (B.ent_cap + 4);
                 for (uint32_t k = tid; k < cn; k += 64) { /* (an entry is at least one bit: the first 32 cover the word) */
                     const uint32_t o = obase + of[k], len = of[k + 1] - of[k];
                     if (__ballot(o < 32u * w1) == 0ull) break;
                     if (len == 0 || o >= 32u * w1) continue;
-                    const uint32_t e = B.ent_list[sg * B.ent_cap + k];
+                    const uint32_t e = len > 128u ? B.ent_list[sg * B.ent_cap + k] : 0u;
                     ent_or_into(s_win, w0, w1, o, len, B.ent_head[sg * B.ent_cap + k], mbb + (size_t)(e >> 5) * VENC_MB_WORDS + (e & 31u) * VENC_LANE_WORDS);
                 }
                 obase += B.seg_bits[sg];
@@ -393,13 +432,13 @@ __global__ __launch_bounds__(ENT_THREADS) void k_pack_p(venc_geom g, venc_bufs B
     }
 }
 
-/* debug / tests (venc_debug_read selector 3): bits per macroblock of a P picture = the sum of its entries' lengths */
+/* debug / tests (venc_debug_read selector 3): bits per macroblock of a P picture = the span of its entries' offsets */
 __global__ __launch_bounds__(ENT_THREADS) void k_entry_mbbits(venc_geom g, venc_bufs B, venc_step S, int v) {
     const int s = S.slice0 + blockIdx.y, j = blockIdx.x;
     const int first = B.slice_first_row[s] * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
-    if (j * ENT_SEG_MBS >= last - first) return;
-    const size_t seg = ent_seg(g, B, v, s, j);
-    const uint32_t count = min(B.ent_count[4 * seg], B.ent_cap);
-    const uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
-    for (uint32_t k = threadIdx.x; k < count; k += ENT_THREADS) atomicAdd(&B.mbnbits[(size_t)v * g.nmb + (B.ent_list[seg * B.ent_cap + k] >> 5)], off[k + 1] - off[k]);
+    const int mb = first + j * ENT_SEG_MBS + (int)threadIdx.x;
+    if (mb >= last) return;
+    const uint32_t *off = B.ent_off + ent_seg(g, B, v, s, j) * (B.ent_cap + 4);
+    const uint32_t m0 = B.ent_mb0[(size_t)v * g.nmb + mb], r0 = m0 & 0xffffu, n = m0 >> 16;
+    B.mbnbits[(size_t)v * g.nmb + mb] = off[r0 + n] - off[r0];
 }

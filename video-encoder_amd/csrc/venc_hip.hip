@@ -312,6 +312,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.codedmask);
     (void)hipFree(c->b.ent_list);
     (void)hipFree(c->b.ent_cls);
+    (void)hipFree(c->b.ent_mb0);
     (void)hipFree(c->b.ent_count);
     (void)hipFree(c->b.ent_head);
     (void)hipFree(c->b.ent_off);
@@ -583,6 +584,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         OPEN_OK(hipMalloc(&b.codedmask, GV * g.n_slices * b.ent_wps * 8));
         OPEN_OK(hipMalloc(&b.ent_list, nseg * b.ent_cap * 4));
         OPEN_OK(hipMalloc(&b.ent_cls, nseg * b.ent_cap * 4));
+        OPEN_OK(hipMalloc(&b.ent_mb0, GV * nmb * 4));
         OPEN_OK(hipMalloc(&b.ent_count, nseg * 16));
         OPEN_OK(hipMemset(b.ent_count, 0, nseg * 16));
         OPEN_OK(hipMalloc(&b.ent_head, nseg * b.ent_cap * sizeof(uint4)));
@@ -1189,10 +1191,9 @@ static int entropy_flush(venc_ctx *c) {
     if (is_idr)
         hipLaunchKernelGGL(k_cavlc, dim3((band_mbs + CAVLC_MBS - 1) / CAVLC_MBS, 1, nv), dim3(256), 0, s2, g, b, S);
     else {
-        /* P pictures (venc_cavlc_p.hip): one block per segment of 256 macroblocks of a slice in all three kernels */
+        /* P pictures (venc_cavlc_p.hip): one block per segment of 256 macroblocks of a slice in both kernels */
         const dim3 eg(c->b.ent_spp, band_slices, nv);
-        hipLaunchKernelGGL(k_skip2, eg, dim3(ENT_SEG_MBS), 0, s2, g, b, S);
-        hipLaunchKernelGGL(k_cavlc_p2, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (((size_t)c->b.ent_cap * 2 + 15) & ~(size_t)15), s2, g, b, S);
+        hipLaunchKernelGGL(k_entropy_p, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (((size_t)c->b.ent_cap + 7) >> 3) * 16 + (size_t)ENT_CLS_LDS * 4, s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {
@@ -1496,7 +1497,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
             }
             src = c->b.mbnbits + item * nmb, n = nmb * 4;
             break;
-        case 16: src = c->b.ent_count + (size_t)item * g.n_slices * c->b.ent_spp * 4, n = (size_t)g.n_slices * c->b.ent_spp * 16; break; /* P pictures: per segment entries, headers, blocks with a level, - */
+        case 16: src = c->b.ent_count + (size_t)item * g.n_slices * c->b.ent_spp, n = (size_t)g.n_slices * c->b.ent_spp * 4; break; /* P pictures: entries per segment */
         case 18: src = c->b.ent_list + (size_t)item * g.n_slices * c->b.ent_spp * c->b.ent_cap, n = (size_t)g.n_slices * c->b.ent_spp * c->b.ent_cap * 4; break;
         case 19: src = c->b.ent_off + (size_t)item * g.n_slices * c->b.ent_spp * (c->b.ent_cap + 4), n = (size_t)g.n_slices * c->b.ent_spp * (c->b.ent_cap + 4) * 4; break;
         case 20: src = c->b.ent_cls + (size_t)item * g.n_slices * c->b.ent_spp * c->b.ent_cap, n = (size_t)g.n_slices * c->b.ent_spp * c->b.ent_cap * 4; break;

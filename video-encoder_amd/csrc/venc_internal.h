@@ -114,13 +114,14 @@ typedef struct {
      * (v * n_slices + s) * ent_spp + j.  Per segment: its syntax entries in bitstream order (mb << 5 | slot), their bit strings'
      * first four words, their bit offsets inside the segment (count + 1 of them), the segment's bits. */
     unsigned long long *codedmask; /* [G][n_slices][ent_wps] bit = macroblock (slice-relative index) is coded (not P_Skip), k_skip2 */
-    uint32_t *ent_list;         /* [segments][ent_cap] bitstream order: mb << 5 | slot */
-    uint32_t *ent_cls;          /* [segments][ent_cap] sorted by kind (headers | blocks with a level | empty blocks): rank << 13 | macroblock of the segment << 5 | slot */
-    uint32_t *ent_count;        /* [segments][4] entries, headers, blocks with a level, - */
+    uint32_t *ent_list;         /* [segments][ent_cap] mb << 5 | slot of the entries whose strings run beyond 128 bits (the others: not written) */
+    uint32_t *ent_cls;          /* [segments][ent_cap] phase B's list of k_entropy_p beyond what its LDS holds */
+    uint32_t *ent_count;        /* [segments] entries */
+    uint32_t *ent_mb0;          /* [G][nmb] rank of the macroblock's first entry | its entries << 16 (debug / tests) */
     uint4 *ent_head;            /* [segments][ent_cap] */
     uint32_t *ent_off;          /* [segments][ent_cap + 4] */
     uint32_t *seg_bits;         /* [segments] */
-    uint32_t ent_cap;           /* entries a segment can hold: 27 x min(256, macroblocks of the largest slice) */
+    uint32_t ent_cap;           /* entries a segment can hold: 28 x min(256, macroblocks of the largest slice) */
     int ent_spp;                /* segments per slice (of the largest slice) */
     int ent_wps;                /* mask words per slice: 4 x ent_spp */
     uint32_t *slice_bits;       /* [G][VENC_MAX_SLICES] bits of every slice of the step (k_scan: per-slice blocks -> the block that builds the table) */
