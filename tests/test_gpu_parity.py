@@ -22,9 +22,9 @@ def _clip(venc, w, h, n, seed, kind):
     return noise_frames(w, h, n, seed)
 
 
-def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x1234ABCD):
+def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x1234ABCD, lib=None):
     enc = orc.Encoder(w, h, qp=qp, n_slices=slices, keyint=keyint, threads=8)
-    eng = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2)
+    eng = venc.Engine(w, h, qp=qp, n_slices=slices, max_items=1, in_slots=2, out_slots=2, lib=lib)
     frames = _clip(venc, w, h, n, seed, kind)
     for t, (y, u, v) in enumerate(frames):
         ref = enc.encode(y, u, v)
@@ -83,6 +83,18 @@ def _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind="synth", seed=0x
 ])
 def test_stages_match_oracle(venc, orc, w, h, qp, slices, keyint, n, kind):
     _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind)
+
+
+@pytest.mark.parametrize("w,h,qp,slices,keyint,n,kind", [
+    (352, 288, 26, 4, 4, 4, "synth"),
+    (1920, 1088, 20, 8, 2, 2, "synth"),    # dense residual: ~20 entries per macroblock
+    (176, 144, 12, 1, 3, 3, "noise"),      # minimum QP, one slice: strings beyond 128 bits among them
+])
+def test_entropy_segments_beyond_their_lds_part(venc, legacy_lib, orc, w, h, qp, slices, keyint, n, kind):
+    """k_entropy_p keeps the lengths of a segment's first ENT_LEN_LDS entries and the first ENT_CLS_LDS of its phase-B list in LDS
+    and sends the rest through memory (lengths park in the upper half of the segment's offsets).  The product sizes both for
+    ordinary pictures; the test-only library is built with 64 / 16, so every segment here runs mostly on the memory paths."""
+    _stage_compare(venc, orc, w, h, qp, slices, keyint, n, kind, lib=legacy_lib)
 
 
 def _x264_stream(venc, frames, w, h, **kw):

@@ -69,9 +69,21 @@ DEVFN uint32_t nc_bytes4(uint32_t A, uint32_t Bv, uint32_t mA, uint32_t mB) {
  * PHASE C: exclusive scan of all lengths (LDS) = the entries' bit offsets inside the segment.
  * An entry's string leaves as ONE 16-byte store (venc_bitsink4: four words in registers; the rare entry beyond 128 bits spills
  * into the macroblock's region of mbbits and says so in ent_list).
- * Dynamic LDS: 36 bytes per lane (the 16 levels of the block being coded + a dword against bank conflicts), 2 bytes per entry
- * the segment can hold (lengths), 4 bytes x ENT_CLS_LDS (the list of phase B; longer lists continue in memory). */
-#define ENT_CLS_LDS 2048
+ * Dynamic LDS: 36 bytes per lane (the 16 levels of the block being coded + a dword against bank conflicts), 2 bytes x ENT_LEN_LDS
+ * (lengths), 4 bytes x ENT_CLS_LDS (the list of phase B); longer segments continue in memory. */
+#ifndef ENT_CLS_LDS
+#define ENT_CLS_LDS 1024 /* entries of phase B's list kept in LDS */
+#endif
+#ifndef ENT_LEN_LDS
+#define ENT_LEN_LDS 3072 /* entries whose lengths are kept in LDS (12 per macroblock; a segment of the 1080p clip has 600 .. 2600) */
+#endif
+/* (a block of this kernel holds the place of a motion-search block on its CU -- the search takes a CU's whole LDS -- so its LDS is
+ * sized for ordinary pictures, 20 KB, not for the worst case, 40 KB; what does not fit goes through memory: same results) */
+#define ENT_LEN_PUT(rank, val)                                   \
+    do {                                                         \
+        if ((rank) < ENT_LEN_LDS) s_len[rank] = (uint16_t)(val); \
+        else len_mem[rank] = (uint16_t)(val);                    \
+    } while (0)
 __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_bufs B, venc_step S) {
     extern __shared__ uint32_t s_dyn[];
     __shared__ uint16_t s_tab[VENC_TAB_SIZE];
@@ -84,7 +96,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     if (j * ENT_SEG_MBS >= last - first) return;
     lds_u32 *strip = (lds_u32 *)(s_dyn + tid * 9); /* (written as dwords, read by the coder as int16: may_alias, see venc_kernels.hip) */
     uint16_t *s_len = (uint16_t *)(s_dyn + ENT_THREADS * 9);
-    uint32_t *s_cls = s_dyn + ENT_THREADS * 9 + ((B.ent_cap + 7u) >> 3) * 4u; /* (behind the lengths, 16-byte aligned) */
+    uint32_t *s_cls = s_dyn + ENT_THREADS * 9 + ENT_LEN_LDS / 2;
     const int mb_seg = first + j * ENT_SEG_MBS;
     const int mb = mb_seg + tid;
     const bool in = mb < last;
@@ -172,6 +184,8 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     const uint32_t count = ta & 0xffffu, n_r_all = tr, n_rn = tr + (ta >> 16);
     uint4 *head = B.ent_head + seg * B.ent_cap;
     uint32_t *cls_mem = B.ent_cls + seg * B.ent_cap, *list = B.ent_list + seg * B.ent_cap;
+    uint16_t *len_mem = (uint16_t *)(B.ent_off + seg * (B.ent_cap + 4)) + 2 * (B.ent_cap + 4) - B.ent_cap - 8; /* (lengths beyond the LDS part park in the upper half of the segment's
+                                                                                                                  offsets, which phase C fills from below: rank k's offset is written after every length <= k was read) */
     if (in) B.ent_mb0[(size_t)v * g.nmb + mb] = (xa & 0xffffu) | (n_all << 16); /* (debug / tests: the macroblock's entries are ranks [lo, lo + hi)) */
     if (em) {
         uint32_t rank = xa & 0xffffu, pos_r = xr, pos_n = tr + (xa >> 16);
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                 venc_bs_se(&bs, (dy - pyv) << (g.subpel ? 0 : 2));
                 venc_bs_ue(&bs, venc_cbp_inter_code[cbp]);
                 if (cbp) venc_bs_se(&bs, 0);
-                s_len[rank] = (uint16_t)venc_bs_flush(&bs);
+                ENT_LEN_PUT(rank, venc_bs_flush(&bs));
                 head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
             } else {
                 uint32_t nC;
@@ -221,7 +235,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                     pos_n++;
                 } else { /* coeff_token of TotalCoeff 0 (table 9-5): 1, 11, 1111, 0000 11 for nC < 2, < 4, < 8, >= 8 */
                     const uint32_t len = nC < 2u ? 1u : nC < 4u ? 2u : nC < 8u ? 4u : 6u;
-                    s_len[rank] = (uint16_t)len;
+                    ENT_LEN_PUT(rank, len);
                     head[rank] = make_uint4((nC < 8u ? 0xffffffffu : 0x0c000000u) << (nC < 8u ? 32u - len : 0u), 0u, 0u, 0u);
                 }
             }
@@ -257,7 +271,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             venc_bs_ue(&bs, skipped ? run + 1u : run); /* (a slice that ends in skipped macroblocks carries their count as a last mb_skip_run) */
         }
         const int bits = venc_bs_flush(&bs);
-        s_len[rank] = (uint16_t)bits;
+        ENT_LEN_PUT(rank, bits);
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
         if (bits > 128) list[rank] = (uint32_t)mbk << 5;
     }
@@ -286,7 +300,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mbk) * VENC_MB_WORDS + slot * VENC_LANE_WORDS);
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, firstc, maxc, nC, s_tab);
         const int bits = venc_bs_flush(&bs);
-        s_len[rank] = (uint16_t)bits;
+        ENT_LEN_PUT(rank, bits);
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
         if (bits > 128) list[rank] = ((uint32_t)mbk << 5) | (uint32_t)slot;
     }
@@ -297,7 +311,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     int phase = 0;
     for (uint32_t k0 = 0; k0 < count; k0 += ENT_THREADS, phase ^= 1) {
         const uint32_t k = k0 + (uint32_t)tid;
-        const uint32_t bits = k < count ? (uint32_t)s_len[k] : 0u;
+        const uint32_t bits = k >= count ? 0u : k < ENT_LEN_LDS ? (uint32_t)s_len[k] : (uint32_t)len_mem[k];
         const uint32_t incl = wave_scan_incl(bits);
         if (lane == 63) s_wtot[phase][tid >> 6] = incl;
         __syncthreads();

@@ -1193,7 +1193,7 @@ static int entropy_flush(venc_ctx *c) {
     else {
         /* P pictures (venc_cavlc_p.hip): one block per segment of 256 macroblocks of a slice in both kernels */
         const dim3 eg(c->b.ent_spp, band_slices, nv);
-        hipLaunchKernelGGL(k_entropy_p, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (((size_t)c->b.ent_cap + 7) >> 3) * 16 + (size_t)ENT_CLS_LDS * 4, s2, g, b, S);
+        hipLaunchKernelGGL(k_entropy_p, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (size_t)ENT_LEN_LDS * 2 + (size_t)ENT_CLS_LDS * 4, s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {
