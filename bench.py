@@ -503,6 +503,7 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                 if slices_mode:  # rank 0 searches only its band
                     r0, r1 = venc.Engine.view(enc.L.x264_venc_engine(enc.h)).band_rows(*dmod.slice_band(wl["slices"], world, 0))
                     px_per_launch *= (r1 - r0) * 16.0 / h
+                px_per_launch /= venc.hip_lib().venc_search_split(enc.L.x264_venc_engine(enc.h))  # two chains: a timed launch searches half the items
                 algo_bytes = ME_ALGO_BYTES_PER_PX * px_per_launch
                 avg_s = me_ms / me_n * 1e-3
                 achieved = algo_bytes / avg_s / 1e9

@@ -221,6 +221,9 @@ int venc_profile(venc_ctx *c, int enable, int capacity);
  * launch of each (default: 1); every pair costs the stream a few microseconds, so the timed region of
  * bench.py samples the dominant kernel only */
 int venc_profile_select(venc_ctx *c, unsigned kernel_mask, int stride);
+/* launches the motion search of a full P step goes as: 1, or 2 with two chains (VENC_CHAINS=2: half the items per launch, the
+ * second half on a stream of its own) -- what one timed "k_me" launch covers */
+int venc_search_split(const venc_ctx *c);
 int venc_profile_kernels(void);
 const char *venc_profile_name(int kernel_id);
 int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches);

@@ -163,6 +163,7 @@ def bind_hip(L):
         L.venc_band_chunk_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.venc_band_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
         L.venc_band_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.venc_search_split.argtypes = [C.c_void_p]
         L.venc_stream_handle.restype = C.c_void_p
         L.venc_stream_handle.argtypes = [C.c_void_p]
         L.venc_rccl_unique_id.argtypes = [C.c_void_p]

@@ -437,7 +437,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_pack_p(venc_geom g, venc_bufs B
                 obase += B.seg_bits[sg];
             }
         }
-        if (last_seg && tid == 0 && (T >> 5) >= w0 && (T >> 5) < w1) atomicOr(&s_win[(T >> 5) - w0], 0x80000000u >> (T & 31u)); /* rbsp_stop_one_bit */
+        /* rbsp_stop_one_bit: by whichever block owns the word that holds bit T (the last segment's when the slice ends on a word
+         * boundary; an earlier one's when the segments behind it are short: a slice that ends in skipped macroblocks) */
+        if (tid == 0 && (T >> 5) >= w0 && (T >> 5) < w1) atomicOr(&s_win[(T >> 5) - w0], 0x80000000u >> (T & 31u));
         __syncthreads();
         for (uint32_t q = tid; q < w1 - w0; q += ENT_THREADS) {
             if (byte_off + 4u * (w0 + q + 1u) > B.out_cap) break;

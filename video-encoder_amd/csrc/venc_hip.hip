@@ -79,6 +79,20 @@ struct venc_ctx {
     venc_geom g;
     venc_bufs b;
     hipStream_t stream;  /* main chain: ingest, k_me, k_me_fix, k_inter / k_intra */
+    /* TWO CHAINS (round 4).  The items of a P step are independent prediction chains, and the launch between two searches -- k_me_fix:
+     * the exhaustive redo and the follow-up of the deferred transform, a few hundred blocks, 13-17 us of dependent latency -- leaves
+     * the chip nearly idle on the critical path.  With two_chain the items' first half runs search -> fix -> search ... on `stream`,
+     * the second half the same on `stream_b`: one half's fix runs beside the other half's search.  Everything else that follows the
+     * main chain (side chain, intra steps running ahead, ring waits) waits for both.  Eligible steps: whole pictures, the deferred
+     * transform, no in-loop filter / refinement / exchange on the main chain; any other step joins stream_b into `stream` first. */
+    hipStream_t stream_b;
+    hipEvent_t ev_b;
+    int two_chain;  /* VENC_CHAINS=2 */
+    int b_active;   /* stream_b carries work the main stream has not waited for */
+    int b_behind;   /* the main stream ran something stream_b's next search depends on (a step that was not split, a band import, an intra
+                       step on the main stream): the next split step makes stream_b wait for the main stream first */
+    int last_n_a;   /* items of the main stream's half in the last split step (another split: the chains resynchronise) */
+    hipEvent_t ev_a;
     hipStream_t stream2; /* entropy chain of the same step: k_cavlc, k_scan, k_pack -- overlaps the next step's main chain */
     hipStream_t stream_copy; /* host -> HBM ingest (venc_upload): overlaps both kernel chains; the main chain waits for a slot's copy
                                 event only when a step reads that slot */
@@ -135,8 +149,8 @@ struct venc_ctx {
      * chroma transforms (stream 2): what an intra step running ahead waits for */
     struct {
         long long last_step;
-        hipEvent_t ev_main, ev_chroma;
-        int has_chroma;
+        hipEvent_t ev_main, ev_chroma, ev_main_b;
+        int has_chroma, has_b;
     } bh[VENC_BHIST];
     int bh_next;
     long long step_no; /* steps issued so far; ring slot of a step = step_no % VENC_RING */
@@ -250,6 +264,13 @@ static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, cons
 }
 /* the chroma transform of the last P step runs on the second stream: anything on the main stream that touches chroma
  * reconstructions (intra pictures, band export / import) waits for it */
+/* two chains: the main stream waits for what the second chain still has in flight */
+static hipError_t main_joins_b(venc_ctx *c) {
+    if (!c->b_active) return hipSuccess;
+    c->b_active = 0;
+    hipError_t e = hipEventRecord(c->ev_b, c->stream_b);
+    return e != hipSuccess ? e : hipStreamWaitEvent(c->stream, c->ev_b, 0);
+}
 static hipError_t main_waits_for_chroma(venc_ctx *c) {
     if (!c->chroma_pending) return hipSuccess;
     c->chroma_pending = 0;
@@ -270,6 +291,7 @@ extern "C" void venc_close(venc_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream && c->stream2 && c->b.mbbits) (void)entropy_flush(c);
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rccl_release(c);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -296,7 +318,11 @@ extern "C" void venc_close(venc_ctx *c) {
     for (int i = 0; i < VENC_BHIST; i++) {
         if (c->bh[i].ev_main) (void)hipEventDestroy(c->bh[i].ev_main);
         if (c->bh[i].ev_chroma) (void)hipEventDestroy(c->bh[i].ev_chroma);
+        if (c->bh[i].ev_main_b) (void)hipEventDestroy(c->bh[i].ev_main_b);
     }
+    if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->stream3) (void)hipStreamDestroy(c->stream3);
     for (int i = 0; i < VENC_RING; i++)
         if (c->ev_side[i]) (void)hipEventDestroy(c->ev_side[i]);
@@ -418,24 +444,35 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         }                           \
     } while (0)
 
-    OPEN_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    /* VENC_PRIO=1 (experiment): the main chain's stream at the highest priority, the side chain's at the lowest */
+    static const int prio = getenv("VENC_PRIO") ? atoi(getenv("VENC_PRIO")) : 0;
+    int prio_lo = 0, prio_hi = 0;
+    OPEN_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    if (prio)
+        OPEN_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_hi));
+    else
+        OPEN_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     {
         /* VENC_ENTROPY_CUS=n: the entropy chain's stream may only use n of the chip's CUs (queue CU mask; the mask bits
          * interleave the XCDs, so the first n bits are n/8 CUs of every XCD).  The chain is latency bound and its
          * blocks otherwise land on every CU, where their LDS and registers cost the motion search its third block. */
-        /* Default: half the chip when a step carries so many macroblocks that the confined chain is still much shorter
-         * than the main chain (2160p x 10 items: main chain ~470 us per step, entropy chain ~160 us free, ~280 us on 128
-         * CUs; the search beside it 330 -> 297 us, +4 % on the pass).  At 1080p x 10 items the confined chain would be
-         * the longer one (measured: -10 %), so no mask there.  VENC_ENTROPY_CUS=0 / =n overrides. */
+        /* Default (round 4, same-box medians of three rounds, gpurun_out/r04_cus2*): 192 of the 256 CUs from 60 000 macroblocks per
+         * step (1080p x 10 items: 166.5 Gpx/s unmasked, 163.6 on 128, 175.6 on 192, 176.9 on 224), 160 from 200 000 (2160p x 10: 208.5
+         * unmasked, 220.0 on 128, 219.6 on 160, 217.4 on 192).  In round 3, with a side chain a quarter heavier, a mask LOST at 1080p;
+         * the chain is light enough now to live on three quarters of the chip, and the search keeps a quarter to itself.  Smaller
+         * steps (streaming engines) stay unmasked.  VENC_ENTROPY_CUS=0 / =n overrides. */
         const char *e = getenv("VENC_ENTROPY_CUS");
-        const int ncu = e ? atoi(e) : ((long long)g.nmb * cfg->max_items >= 200000 ? 192 : 0); /* (round 3, with the search on four blocks per CU: 2160p x 10 items 206.9 Gpx/s unmasked, 201.0 on 256 (a masked queue), 211.8 on 192, 143.6 on 64; round 2 with three blocks per CU chose 128) */
+        const long long step_mbs = (long long)g.nmb * cfg->max_items;
+        const int ncu = e ? atoi(e) : step_mbs >= 200000 ? 160 : step_mbs >= 60000 ? 192 : 0;
         hipDeviceProp_t prop;
         OPEN_OK(hipGetDeviceProperties(&prop, cfg->device));
         if (ncu >= 8 && ncu < prop.multiProcessorCount) {
             uint32_t mask[16] = {0};
             for (int i = 0; i < ncu && i < 512; i++) mask[i >> 5] |= 1u << (i & 31);
             OPEN_OK(hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)((prop.multiProcessorCount + 31) / 32), mask));
-        } else
+        } else if (prio)
+            OPEN_OK(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio_lo));
+        else
             OPEN_OK(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     }
     OPEN_OK(hipStreamCreateWithFlags(&c->stream_copy, hipStreamNonBlocking));
@@ -464,8 +501,14 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     for (int i = 0; i < VENC_BHIST; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_main, hipEventDisableTiming));
         OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_chroma, hipEventDisableTiming));
+        OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_main_b, hipEventDisableTiming));
         c->bh[i].last_step = -1;
     }
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    OPEN_OK(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    OPEN_OK(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+    c->b_behind = 1;
+    c->two_chain = getenv("VENC_CHAINS") ? atoi(getenv("VENC_CHAINS")) == 2 : 0;
     c->intra_ahead = !(getenv("VENC_INTRA_AHEAD") && atoi(getenv("VENC_INTRA_AHEAD")) == 0);
     c->rec_last = VENC_RECON - 1;
     /* 0: k_inter_fused (luma + chroma) on the main chain; 1 (default): luma transform inside the search kernels, chroma on stream 2;
@@ -878,6 +921,21 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     const int band_rows = S.row1 - S.row0, band_mbs = S.mb1 - S.mb0, band_slices = S.slice1 - S.slice0;
     /* intra steps run ahead on a third stream (VENC_RECON) unless the engine codes a band or the legacy kernel */
     const bool intra_async = is_idr && c->intra_ahead && c->overlap && !c->intra_legacy && c->me_mode == 0 && !c->rc_comm && c->band_s0 == 0 && c->band_s1 == c->g.n_slices;
+    /* two chains (see venc_ctx): this P step's items [0, n_a) on the main stream, [n_a, n_items) on stream_b */
+    static const int me_blocks_env = getenv("VENC_ME_BLOCKS") ? atoi(getenv("VENC_ME_BLOCKS")) : 4;
+    const bool two = c->two_chain && !is_idr && c->overlap && n_items >= 2 && c->me_mode == 0 && !c->inter_legacy && c->fuse_luma == 3 && me_blocks_env != 3 && !c->g.subpel &&
+                     !c->cfg.deblock && !c->rc_comm && c->band_s0 == 0 && c->band_s1 == c->g.n_slices && !c->me_xcd;
+    const int n_a = two ? (n_items + 1) / 2 : n_items;
+    if (!two) {
+        HIP_OK(main_joins_b(c));
+        c->b_behind = 1;
+    } else if (c->b_behind || c->last_n_a != n_a) { /* both ways: the main stream has what stream_b did, stream_b waits for what the main stream has enqueued */
+        HIP_OK(main_joins_b(c));
+        HIP_OK(hipEventRecord(c->ev_a, c->stream));
+        HIP_OK(hipStreamWaitEvent(c->stream_b, c->ev_a, 0));
+        c->b_behind = 0;
+        c->last_n_a = n_a;
+    }
     for (int i = 0; i < n_items; i++) {
         if (in_slots[i] < 0 || in_slots[i] >= c->in_frames || out_slots[i] < 0 || out_slots[i] >= c->cfg.out_slots) {
             SET_ERR("venc_encode_step: slot out of range (item %d: in %d, out %d)", i, in_slots[i], out_slots[i]);
@@ -887,7 +945,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         S.out_slot[i] = out_slots[i];
         if (c->staged) c->fetched[out_slots[i]] = 0;
         if (c->d_in && c->b.in_base == c->d_in && c->copy_pending[in_slots[i]]) { /* the frame's ingest copy precedes the step */
-            HIP_OK(hipStreamWaitEvent(intra_async ? c->stream3 : c->stream, c->ev_copy[in_slots[i]], 0));
+            HIP_OK(hipStreamWaitEvent(intra_async ? c->stream3 : i >= n_a ? c->stream_b : c->stream, c->ev_copy[in_slots[i]], 0));
             c->copy_pending[in_slots[i]] = 0;
         }
         S.idr_id[i] = idr_ids ? idr_ids[i] : 0;
@@ -931,11 +989,15 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         /* the next WAIT steps overwrite the ring slots of steps step_no - RING .. step_no - RING + WAIT - 1: the entropy
          * batch that read the last of them has been launched (batches never span a group of WAIT slots) and covers the others */
         const long long need = c->step_no + VENC_RING_WAIT - 1 - VENC_RING;
-        if (need >= 0 && c->side_step[need % VENC_RING] == need) HIP_OK(hipStreamWaitEvent(s1, c->ev_side[need % VENC_RING], 0));
+        if (need >= 0 && c->side_step[need % VENC_RING] == need) {
+            HIP_OK(hipStreamWaitEvent(s1, c->ev_side[need % VENC_RING], 0));
+            if (c->two_chain) HIP_OK(hipStreamWaitEvent(c->stream_b, c->ev_side[need % VENC_RING], 0)); /* (the wait covers the next WAIT steps, whichever stream runs them) */
+        }
     }
     /* the first P step after intra steps that ran ahead joins their stream */
     if (!is_idr && c->intra_pending) {
         HIP_OK(hipStreamWaitEvent(s1, c->ev_intra, 0));
+        if (two) HIP_OK(hipStreamWaitEvent(c->stream_b, c->ev_intra, 0));
         c->intra_pending = 0;
     }
     if (is_idr) {
@@ -952,6 +1014,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
                 if (c->bh[i].last_step >= 0 && c->bh[i].last_step >= last_reader && (best < 0 || c->bh[i].last_step < c->bh[best].last_step)) best = i;
             if (best >= 0) {
                 HIP_OK(hipStreamWaitEvent(s1, c->bh[best].ev_main, 0));
+                if (c->bh[best].has_b) HIP_OK(hipStreamWaitEvent(s1, c->bh[best].ev_main_b, 0));
                 if (c->bh[best].has_chroma) HIP_OK(hipStreamWaitEvent(s1, c->bh[best].ev_chroma, 0));
             }
             const long long need = c->step_no - VENC_RING;
@@ -1028,14 +1091,21 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
              * chain waits for whole CUs wherever it may run. */
             static const int me_blocks = getenv("VENC_ME_BLOCKS") ? atoi(getenv("VENC_ME_BLOCKS")) : 4;
             const bool pool4 = me_blocks != 3 && (fuse_arg == 0 || fuse_arg == 3);
-            if (pool4 && c->cfg.rc_mode)
-                hipLaunchKernelGGL(k_me_pool4<true>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
-            else if (pool4)
-                hipLaunchKernelGGL(k_me_pool4<false>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
-            else if (c->cfg.rc_mode)
-                hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
-            else
-                hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, n_items), dim3(512), (size_t)lds_pad, s1, g, b, S, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            for (int half = 0; half < (two ? 2 : 1); half++) {
+                venc_step Sh = S;
+                Sh.item0 = half ? n_a : 0;
+                const int nh = two ? (half ? n_items - n_a : n_a) : n_items;
+                hipStream_t sh = half ? c->stream_b : s1;
+                if (half) prof_end(c, s1); /* (the timed launches are the main stream's: half the items) */
+                if (pool4 && c->cfg.rc_mode)
+                    hipLaunchKernelGGL(k_me_pool4<true>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                else if (pool4)
+                    hipLaunchKernelGGL(k_me_pool4<false>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                else if (c->cfg.rc_mode)
+                    hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                else
+                    hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+            }
             if (fuse_arg == 3) nz_regions = 4 * ntx * nty, nz_ntx = ntx, nz_magic = tx_magic;
         }
         prof_end(c, s1);
@@ -1048,10 +1118,18 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             const int nz_blocks = (nz_regions + nz_rpb - 1) / nz_rpb;
             const int nz_rpt = (((nz_regions + 64 * FIX_WAVES - 1) / (64 * FIX_WAVES)) + 3) & ~3;
             const size_t fix_lds = nz_blocks ? (size_t)64 * FIX_WAVES * nz_rpt : 0;
-            if (c->cfg.rc_mode)
-                hipLaunchKernelGGL(k_me_fix<true>, dim3(n_items, nz_blocks + FIX_BLOCKS, 1), dim3(64 * FIX_WAVES), fix_lds, s1, g, b, S, fuse_arg, nz_blocks, nz_regions, nz_rpt, nz_ntx, nz_magic);
-            else
-                hipLaunchKernelGGL(k_me_fix<false>, dim3(n_items, nz_blocks + FIX_BLOCKS, 1), dim3(64 * FIX_WAVES), fix_lds, s1, g, b, S, fuse_arg, nz_blocks, nz_regions, nz_rpt, nz_ntx, nz_magic);
+            for (int half = 0; half < (two ? 2 : 1); half++) {
+                venc_step Sh = S;
+                Sh.item0 = half ? n_a : 0;
+                const int nh = two ? (half ? n_items - n_a : n_a) : n_items;
+                hipStream_t sh = half ? c->stream_b : s1;
+                if (half) prof_end(c, s1);
+                if (c->cfg.rc_mode)
+                    hipLaunchKernelGGL(k_me_fix<true>, dim3(nh, nz_blocks + FIX_BLOCKS, 1), dim3(64 * FIX_WAVES), fix_lds, sh, g, b, Sh, fuse_arg, nz_blocks, nz_regions, nz_rpt, nz_ntx, nz_magic);
+                else
+                    hipLaunchKernelGGL(k_me_fix<false>, dim3(nh, nz_blocks + FIX_BLOCKS, 1), dim3(64 * FIX_WAVES), fix_lds, sh, g, b, Sh, fuse_arg, nz_blocks, nz_regions, nz_rpt, nz_ntx, nz_magic);
+            }
+            if (two) c->b_active = 1;
             prof_end(c, s1);
         }
 #ifdef VENC_LEGACY_KERNELS
@@ -1159,6 +1237,11 @@ static int entropy_flush(venc_ctx *c) {
         } else {
             HIP_OK(hipEventRecord(c->bh[hi].ev_main, s1));
             HIP_OK(hipStreamWaitEvent(s2, c->bh[hi].ev_main, 0));
+            c->bh[hi].has_b = c->b_active;
+            if (c->b_active) { /* (the second chain stays ahead of the main stream: only the side chain waits for it here) */
+                HIP_OK(hipEventRecord(c->bh[hi].ev_main_b, c->stream_b));
+                HIP_OK(hipStreamWaitEvent(s2, c->bh[hi].ev_main_b, 0));
+            }
             c->bh[hi].last_step = c->eb_first_step + n_steps - 1;
             c->bh[hi].has_chroma = 0;
             c->bh_next = (hi + 1) % VENC_BHIST;
@@ -1246,6 +1329,7 @@ extern "C" int venc_set_band(venc_ctx *c, int slice_first, int slice_count) {
         return -1;
     }
     if (entropy_flush(c) != 0) return -1;
+    HIP_OK(main_joins_b(c));
     c->band_s0 = slice_first;
     c->band_s1 = slice_first + slice_count;
     return 0;
@@ -1304,6 +1388,8 @@ static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride
     }
     HIP_OK(hipSetDevice(c->cfg.device));
     if (entropy_flush(c) != 0) return -1; /* (the chroma transforms of an open batch are launched with it) */
+    HIP_OK(main_joins_b(c));
+    c->b_behind = 1;
     HIP_OK(main_waits_for_chroma(c));
     J.to_chunk = to_chunk;
     J.item_stride = item_stride;
@@ -1332,6 +1418,8 @@ extern "C" int venc_band_import(venc_ctx *c, int n_items, const void *d_chunk, s
 }
 
 extern "C" void *venc_stream_handle(venc_ctx *c) { return (void *)c->stream; }
+/* launches the search of a full P step is split into (1, or 2 with two chains): what a timed k_me launch covers */
+extern "C" int venc_search_split(const venc_ctx *c) { return c->two_chain ? 2 : 1; }
 
 extern "C" int venc_mark(venc_ctx *c) {
     const int t = c->ev_next;
@@ -1381,6 +1469,8 @@ extern "C" int venc_sync(venc_ctx *c) {
     if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream_copy));
     HIP_OK(hipStreamSynchronize(c->stream3));
+    HIP_OK(hipStreamSynchronize(c->stream_b));
+    c->b_active = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     return 0;
@@ -1391,6 +1481,8 @@ extern "C" int venc_sync(venc_ctx *c) {
 extern "C" int venc_set_overlap(venc_ctx *c, int enable) {
     if (entropy_flush(c) != 0) return -1;
     HIP_OK(hipStreamSynchronize(c->stream3));
+    HIP_OK(hipStreamSynchronize(c->stream_b));
+    c->b_active = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     c->chroma_pending = 0;
@@ -1461,6 +1553,8 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
     }
     HIP_OK(hipSetDevice(c->cfg.device));
     if (entropy_flush(c) != 0) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream_b));
+    c->b_active = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     const venc_geom &g = c->g;
@@ -1579,6 +1673,8 @@ extern "C" const char *venc_profile_name(int kid) { return kid >= 0 && kid < KID
 /* sums the recorded launches per kernel (after a stream sync) and resets the log */
 extern "C" int venc_profile_read(venc_ctx *c, double *ms_sum, int *launches) {
     if (entropy_flush(c) != 0) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream_b));
+    c->b_active = 0;
     HIP_OK(hipStreamSynchronize(c->stream));
     HIP_OK(hipStreamSynchronize(c->stream2));
     for (int k = 0; k < KID_COUNT; k++) ms_sum[k] = 0.0, launches[k] = 0;

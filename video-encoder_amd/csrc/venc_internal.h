@@ -69,6 +69,7 @@ typedef struct {
 
 typedef struct {
     int n_items;
+    int item0;   /* first item of this launch (the search kernels: the items of a P step may go as two launches on two streams, venc_hip.hip TWO CHAINS) */
     int deblock; /* the in-loop filter is on: slice headers say so (k_deblock does the filtering) */
     int is_idr;
     int frame_num;

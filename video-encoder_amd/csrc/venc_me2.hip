@@ -134,8 +134,10 @@ __global__ __launch_bounds__(64 * FIX_WAVES) void k_me_fix(venc_geom g, venc_buf
     /* Grid = (items, nz_blocks + FIX_BLOCKS): the item runs fastest in dispatch order, so that the few blocks with work -- the
      * first `count` redo blocks of every item, the follow-up blocks -- are all resident at once instead of queueing behind
      * the 256 redo blocks per item that only load their count and leave (three blocks of this kernel fit a CU). */
-    const int item = blockIdx.x, tid = threadIdx.x;
+    const int item = (int)blockIdx.x + S.item0, tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    __builtin_amdgcn_s_setprio(3); /* (two chains: this launch runs beside the other chain's search, whose eight waves per SIMD would leave its serial
+                                      instruction streams an eighth of the issue slots) */
     /* the first nz_blocks rows of the grid (fuse_luma == 3): the 4x4 blocks the search's P5 listed instead of coding them
      * (venc_inter2.hip luma_block_defer) -- no part in the exhaustive redo or in the closing of the picture's SAD sum */
     if ((int)blockIdx.y < nz_blocks) {

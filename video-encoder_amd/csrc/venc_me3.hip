@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
      * rows or runs of 64 tiles.  The kernel is bound by VALU and LDS, not by these fetches (which the 256 MB last-level
      * cache serves), and neighbours on one XCD pull the same L2 lines at the same time.  Hence off by default; kept for
      * memory-bound company.  Placement is never a correctness matter. */
-    const int item = blockIdx.z;
+    const int item = (int)blockIdx.z + S.item0;
     const int kx = (int)(blockIdx.x >> 3);
     const int tile = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
     if (tile >= tiles_x * tiles_y) return;

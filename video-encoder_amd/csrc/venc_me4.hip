@@ -59,7 +59,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
     const int col0 = mbx * 16, row0 = mby * 16;
     const uint16_t *rank = B.me_rank;
-    const int item = blockIdx.z;
+    const int item = (int)blockIdx.z + S.item0;
     const int kx = (int)(blockIdx.x >> 3);
     const int tile = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
     if (tile >= tiles_x * tiles_y) return;
