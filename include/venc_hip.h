@@ -70,7 +70,8 @@ typedef struct {
 } venc_slice;
 
 typedef struct {
-    const uint8_t *data;      /* pinned host memory, valid until the slot is reused */
+    const uint8_t *data;      /* pinned host memory; engines with max_items > 1 stage their output in HBM and keep a frame's bytes on the host
+                                 until max(8, 4 x max_items) further frames have been fetched -- copy or package them before that */
     const venc_slice *slices; /* n_slices entries */
     uint32_t n_slices;
     uint32_t total_bytes;
@@ -80,6 +81,7 @@ typedef struct {
 int venc_abi_version(void);
 const char *venc_last_error(void);
 int venc_device_count(void);
+int venc_device_memory(int device, size_t *free_bytes, size_t *total_bytes); /* 0 = ok */
 
 int venc_open(const venc_config *cfg, venc_ctx **out);
 void venc_close(venc_ctx *c);

@@ -96,8 +96,18 @@ typedef struct x264_param_t {
     } rc;
     struct {                /* engine extension, not part of libx264 */
         int i_device;       /* HIP device ordinal */
-        int i_gop_batch;    /* closed GOPs encoded in lock-step (1 = frame-by-frame streaming); x264_param_default_preset: 10, or 1 with
-                               tune zerolatency */
+        /* Closed GOPs encoded in lock-step ("items"): 1 = frame-by-frame streaming; 0 (x264_param_default_preset; tune zerolatency:
+         * 1) = chosen by x264_encoder_open: 10, or with the in-loop filter or the Intra4x4 trial on -- whose kernels launch one block
+         * per slice and item -- enough that items x slices reaches the chip's 256 CUs (32 with the default 8 slices).
+         * WHAT IT COSTS THE CALLER.  Delay: x264_encoder_encode returns 0 (av_encode.c:971-974) for the first i_gop_batch x i_keyint_max
+         * pictures (300 / 960 with the defaults) and the rest arrives through the x264_encoder_delayed_frames loop (:1076-1083).
+         * Memory: the encoder pools twice that many pictures in HBM -- per picture its I420 input (1.5 B/px) and an output slot of
+         * 400 bytes per macroblock (the conformance bound), 6.4 MB at 1080p, 25.4 MB at 2160p -- plus ~22 KB per macroblock and item
+         * of working buffers: 3.9 / 12.3 GB at 1080p with 10 / 32 items, 15.5 / 49 GB at 2160p.  Whatever is asked for here or chosen,
+         * x264_encoder_open lowers it until that fits into half of the device's free memory (a long i_keyint_max -- libx264's own
+         * default is 250 -- ends with fewer items, never with a failed open).  Host memory: 40 + pinned output buffers of that slot
+         * size whatever the pool (130 MB at 1080p), and the packaged NAL payloads of the pooled pictures (their real size). */
+        int i_gop_batch;
         int i_gop_base;     /* index of this encoder's first GOP in the whole stream (GOP-sharded multi-GPU runs) */
         /* slice-parallel multi-GPU mode (BASELINE config 5): this encoder codes only
          * the slices [i_slice_first, i_slice_first + i_slice_count) of every picture (0, 0 = all) and calls
@@ -211,6 +221,8 @@ int x264_venc_encode_host_frames(x264_t *h, const uint8_t *frames, uint64_t fram
                                  int repeats, x264_venc_sink sink, void *user);
 /* the venc_ctx* behind an encoder (for venc_profile / venc_debug_read) */
 void *x264_venc_engine(x264_t *h);
+/* closed GOPs the encoder advances in lock-step: hip.i_gop_batch, or what 0 resolved to, after the cap by device memory */
+int x264_venc_gop_batch(x264_t *h);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 frame, through the reference's own entry points (include/x264.h; av_encode.c:970, consumer :670-834).
 
   config 2   1920x1080 x 300 frames, IPPP GOP 30, QP 26, 8 slices: every frame's payload equals the oracle's
-  config 3   3840x2160 x 60 frames (two GOPs in lock-step): every frame's payload equals the oracle's
+  config 3   3840x2160 x 300 frames, the same: every frame's payload equals the oracle's (oracle: one encoder per closed GOP side by side)
   config 4   8 concurrent 1080p streams with seeds base + i (one per GPU in production; here eight encoders share
              the one GPU of the box, fed round-robin like eight live sources)
   config 5   3840x2160 cut into the 8 fixed slice bands 17,17,17,17,17,17,17,16 MB rows, one engine per band (one per

@@ -867,6 +867,41 @@ def test_x264_api_with_every_preset_tool_matches_oracle(venc, orc):
         assert dec.decode(got[t].payload) == 1 and np.array_equal(dec.planes()[0], enc.recon()[0])
 
 
+def test_reference_open_sequence_at_1080p_chooses_its_items_and_matches_oracle(venc, orc):
+    """The reference's own open sequence (av_encode.c:384-401) at the size the metric is quoted on: preset medium, tune film, X264_RC_CRF,
+    nothing else set.  The encoder chooses its GOPs in lock-step itself (32 with eight slices: the wavefront tools' blocks fill the
+    chip), delays its output by that many GOPs and drains through the flush loop; the stream equals the oracle's with the same tools."""
+    w, h, n = 1920, 1080, 34
+    frames = [venc.synth_frame(w, h, t) for t in range(n)]
+    e = venc.X264Encoder(w, h, fps=(30, 1), sar=(1, 1), preset="medium", tune="film", crf=20, reference_defaults=True)
+    assert e.gop_batch() == 32 and e.param.hip.i_deblock == 1 and e.param.hip.i_intra_modes == 3 and e.param.hip.i_subpel == 2
+    keyint, slices = e.param.i_keyint_max, e.param.i_slice_count
+    got = []
+    for t, (y, u, v) in enumerate(frames):
+        r = e.encode(y, u, v, t)
+        assert r is None  # (the unit is 32 GOPs: nothing comes back before the flush)
+    assert e.delayed_frames() == n
+    got = e.flush()
+    e.close()
+    enc = orc.Encoder(w, h, qp=20, n_slices=slices, keyint=keyint, fps=(30, 1), sar=(1, 1), threads=8, rc=True, intra_modes=3, subpel=2, deblock=True)
+    for t, f in enumerate(frames):
+        assert got[t].payload == enc.encode(*f).data, "frame %d" % t
+
+
+def test_long_key_frame_interval_is_capped_by_device_memory_not_a_failed_open(venc):
+    """the unit is gop_batch x keyint frames and the pools twice that; with libx264's own default interval of 250
+    at 2160p the preset's 32 items would ask for 400 GB.  x264_encoder_open lowers the items until the pools fit half of the free
+    device memory; the stream still flows: frames in, the same number out through the flush loop, key frames where they belong."""
+    w, h, n = 3840, 2160, 6
+    e = venc.X264Encoder(w, h, fps=(30, 1), sar=(1, 1), preset="medium", tune="film", crf=23, reference_defaults=True, preset_keyint=250)
+    assert 1 <= e.gop_batch() < 32, e.gop_batch()
+    for t in range(n):
+        assert e.encode(*venc.synth_frame(w, h, t), t) is None
+    out = e.flush()
+    e.close()
+    assert len(out) == n and out[0].keyframe and not any(f.keyframe for f in out[1:]) and [f.pts for f in out] == list(range(n))
+
+
 def test_x264_api_with_intra_modes_and_rate_control(venc, orc):
     """What a C caller gets from x264_param_default_preset + X264_RC_CRF (the reference's open sequence,
     av_encode.c:384-401): Intra16x16 V / H / DC and the CRF approximation together, GOP-batched."""

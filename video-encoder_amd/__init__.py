@@ -496,7 +496,8 @@ class X264Encoder:
 
     def __init__(self, width, height, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(0, 0), preset="medium",
                  tune="film", profile=None, gop_batch=1, device=0, annexb=False, crf=None, gop_base=0,
-                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0, deblock=False, input_depth=1):
+                 slice_first=0, slice_count=0, exchange=None, rccl=None, intra_modes=False, subpel=0, deblock=False, input_depth=1,
+                 reference_defaults=False, preset_keyint=None):
         """slice_first / slice_count / exchange: slice-parallel multi-GPU mode (include/x264.h, hip extension);
         exchange(engine_view, n_items) is called after every picture that a P picture follows.
         rccl = (world, rank, id_bytes, halo_rows): the engine does the exchange itself in C over RCCL
@@ -514,15 +515,21 @@ class X264Encoder:
             p.rc.i_rc_method, p.rc.f_rf_constant = X264_RC_CRF, float(crf)
         else:
             p.rc.i_rc_method, p.rc.i_qp_constant = X264_RC_CQP, qp
-        p.i_keyint_max, p.i_slice_count = keyint, slices
-        p.hip.i_device, p.hip.i_gop_batch, p.hip.i_gop_base = device, gop_batch, gop_base
-        p.hip.i_slice_first, p.hip.i_slice_count = slice_first, slice_count
-        # Intra16x16 V / H / DC by SAD: the C API's preset default is on; this mirror defaults to the DC-only codec
-        # definition that bench.py and the golden fixtures are frozen on
-        p.hip.i_intra_modes = int(intra_modes)
-        p.hip.i_subpel = int(subpel)  # (likewise: the C API's presets refine to quarter samples)
-        p.hip.i_deblock = int(bool(deblock))  # (and filter in the loop)
+        p.hip.i_device = device
         p.hip.i_input_depth = int(input_depth)
+        if not reference_defaults:
+            p.i_keyint_max, p.i_slice_count = keyint, slices
+            p.hip.i_gop_batch, p.hip.i_gop_base = gop_batch, gop_base
+            p.hip.i_slice_first, p.hip.i_slice_count = slice_first, slice_count
+            # Intra16x16 V / H / DC by SAD: the C API's preset default is on; this mirror defaults to the DC-only codec
+            # definition that bench.py and the golden fixtures are frozen on
+            p.hip.i_intra_modes = int(intra_modes)
+            p.hip.i_subpel = int(subpel)  # (likewise: the C API's presets refine to quarter samples)
+            p.hip.i_deblock = int(bool(deblock))  # (and filter in the loop)
+        if preset_keyint is not None:
+            p.i_keyint_max = int(preset_keyint)  # (a caller of libx264 that keeps ITS default key-frame interval, 250)
+        # reference_defaults: ONLY what enc_x264_open sets (av_encode.c:384-401) -- size, b_annexb, frame rate, SAR, rate control --;
+        # key-frame interval, slices, coding tools and the number of GOPs in lock-step stay what x264_param_default_preset chose
         if rccl is not None:
             world, rank, ident, halo = rccl
             p.hip.i_rccl_world, p.hip.i_rccl_rank, p.hip.i_halo_rows = world, rank, halo
@@ -597,6 +604,11 @@ class X264Encoder:
         if size < 0:
             raise self._error("x264: encoder error")
         return self._collect(size, nals, n.value) if size > 0 else None
+
+    def gop_batch(self):
+        """closed GOPs advanced in lock-step: hip.i_gop_batch, or what 0 resolved to, after the cap by device memory"""
+        self.L.x264_venc_gop_batch.argtypes = [C.c_void_p]
+        return self.L.x264_venc_gop_batch(self.h)
 
     def delayed_frames(self):
         return self.L.x264_encoder_delayed_frames(self.h)

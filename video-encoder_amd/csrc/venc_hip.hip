@@ -163,6 +163,15 @@ struct venc_ctx {
                              slow every other kernel's memory traffic while they drain (the search beside an I picture's k_pack ran at
                              a quarter of its speed); HBM stores do neither, and the copy engine moves the bytes without a CU */
     uint8_t *fetched;     /* [out_slots] staged engines: the slot's data is in h_data */
+    /* Staged engines keep the bytes on the host only from the fetch of a step to the packaging of its frames, so the pinned pool is a
+     * small ROTATING set of host buffers, not one per output slot: round 3 pinned out_slots x out_cap (400 bytes per macroblock:
+     * 1.96 GB for the preset's 600 slots at 1080p, 7.8 GB at 2160p, tens of GB for a long keyint) where 40 buffers do.  A frame's bytes
+     * stay valid on the host until host_slots further frames have been fetched.  Only venc_fetch / venc_get_frame touch these
+     * (one thread: the packaging thread, or the caller's in engines without one). */
+    int host_slots;       /* buffers in h_data (direct engines: out_slots, slot = buffer) */
+    int *host_of;         /* [out_slots] buffer that holds the slot's bytes (-1: none) */
+    int *host_owner;      /* [host_slots] slot whose bytes the buffer holds (-1: none) */
+    int host_next;
     hipStream_t stream_d2h;
     venc_slice_out *d_slice;
     int *d_slice_rows;
@@ -279,6 +288,14 @@ static hipError_t main_waits_for_chroma(venc_ctx *c) {
 
 extern "C" int venc_abi_version(void) { return VENC_ABI_VERSION; }
 extern "C" const char *venc_last_error(void) { return g_err; }
+/* free and total memory of a device (the host shim sizes its frame pools by it) */
+extern "C" int venc_device_memory(int device, size_t *free_bytes, size_t *total_bytes) {
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return -1;
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return 0;
+}
 extern "C" int venc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -371,6 +388,8 @@ extern "C" void venc_close(venc_ctx *c) {
     if (c->h_data) (void)hipHostFree(c->h_data);
     (void)hipFree(c->d_data);
     free(c->fetched);
+    free(c->host_of);
+    free(c->host_owner);
     if (c->stream_d2h) (void)hipStreamDestroy(c->stream_d2h);
     if (c->prof_ev)
         for (int i = 0; i < 2 * c->prof_cap; i++)
@@ -743,7 +762,12 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     }
     OPEN_OK(hipHostMalloc((void **)&c->h_hdr, b.out_hdr_stride * cfg->out_slots, hipHostMallocMapped));
     memset(c->h_hdr, 0, b.out_hdr_stride * cfg->out_slots);
-    OPEN_OK(hipHostMalloc((void **)&c->h_data, b.out_data_stride * cfg->out_slots, c->staged ? hipHostMallocDefault : hipHostMallocMapped));
+    c->host_slots = cfg->out_slots;
+    if (c->staged) {
+        const int want = 4 * cfg->max_items > 8 ? 4 * cfg->max_items : 8;
+        c->host_slots = cfg->out_slots < want ? cfg->out_slots : want;
+    }
+    OPEN_OK(hipHostMalloc((void **)&c->h_data, b.out_data_stride * c->host_slots, c->staged ? hipHostMallocDefault : hipHostMallocMapped));
     void *dview = NULL;
     OPEN_OK(hipHostGetDevicePointer(&dview, c->h_hdr, 0));
     b.out_hdr = (uint8_t *)dview;
@@ -751,7 +775,11 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         OPEN_OK(hipMalloc(&c->d_data, b.out_data_stride * cfg->out_slots));
         b.out_data = c->d_data;
         c->fetched = (uint8_t *)calloc((size_t)cfg->out_slots, 1);
-        if (!c->fetched) {
+        c->host_of = (int *)malloc(sizeof(int) * (size_t)cfg->out_slots);
+        c->host_owner = (int *)malloc(sizeof(int) * (size_t)c->host_slots);
+        if (c->host_of) for (int i = 0; i < cfg->out_slots; i++) c->host_of[i] = -1;
+        if (c->host_owner) for (int i = 0; i < c->host_slots; i++) c->host_owner[i] = -1;
+        if (!c->fetched || !c->host_of || !c->host_owner) {
             SET_ERR("venc_open: out of host memory");
             venc_close(c);
             return -1;
@@ -1503,6 +1531,13 @@ extern "C" int venc_fetch(venc_ctx *c, int first_slot, int slot_step, int count)
         SET_ERR("venc_fetch: bad slot range (%d, step %d, count %d)", first_slot, slot_step, count);
         return -1;
     }
+    if (count > c->host_slots) { /* (more frames than host buffers: in runs that fit) */
+        for (int i = 0; i < count; i += c->host_slots) {
+            const int n = count - i < c->host_slots ? count - i : c->host_slots;
+            if (venc_fetch(c, first_slot + i * slot_step, slot_step, n) != 0) return -1;
+        }
+        return 0;
+    }
     uint32_t widest = 0;
     int need = 0;
     for (int i = 0; i < count; i++) {
@@ -1514,12 +1549,23 @@ extern "C" int venc_fetch(venc_ctx *c, int first_slot, int slot_step, int count)
     }
     if (!need) return 0;
     if (widest > c->b.out_cap) widest = c->b.out_cap;
+    /* `count` consecutive host buffers, taken in rotation; whatever they held is no longer on the host */
+    const int h0 = c->host_next + count <= c->host_slots ? c->host_next : 0;
+    c->host_next = (h0 + count) % c->host_slots;
+    for (int i = 0; i < count; i++) {
+        const int slot = first_slot + i * slot_step, old = c->host_owner[h0 + i];
+        if (old >= 0 && c->host_of[old] == h0 + i) c->host_of[old] = -1, c->fetched[old] = 0;
+        if (c->host_of[slot] >= 0 && c->host_owner[c->host_of[slot]] == slot) c->host_owner[c->host_of[slot]] = -1; /* (fetched again: its earlier copy is stale) */
+        c->host_owner[h0 + i] = slot;
+        c->host_of[slot] = h0 + i;
+    }
     if (widest) {
-        const size_t off = (size_t)first_slot * c->b.out_data_stride, pitch = (size_t)slot_step * c->b.out_data_stride;
+        const size_t src = (size_t)first_slot * c->b.out_data_stride, spitch = (size_t)slot_step * c->b.out_data_stride;
+        uint8_t *dst = c->h_data + (size_t)h0 * c->b.out_data_stride;
         if (count == 1)
-            HIP_OK(hipMemcpyAsync(c->h_data + off, c->d_data + off, widest, hipMemcpyDeviceToHost, c->stream_d2h));
+            HIP_OK(hipMemcpyAsync(dst, c->d_data + src, widest, hipMemcpyDeviceToHost, c->stream_d2h));
         else
-            HIP_OK(hipMemcpy2DAsync(c->h_data + off, pitch, c->d_data + off, pitch, widest, (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
+            HIP_OK(hipMemcpy2DAsync(dst, c->b.out_data_stride, c->d_data + src, spitch, widest, (size_t)count, hipMemcpyDeviceToHost, c->stream_d2h));
         HIP_OK(hipStreamSynchronize(c->stream_d2h));
     }
     for (int i = 0; i < count; i++) c->fetched[first_slot + i * slot_step] = 1;
@@ -1534,7 +1580,7 @@ extern "C" int venc_get_frame(venc_ctx *c, int slot, venc_frame *out) {
     const uint8_t *p = c->h_hdr + (size_t)slot * c->b.out_hdr_stride;
     const venc_out_header *h = (const venc_out_header *)p;
     if (c->staged && !c->fetched[slot] && !h->error && venc_fetch(c, slot, 1, 1) != 0) return -1;
-    out->data = c->h_data + (size_t)slot * c->b.out_data_stride;
+    out->data = c->h_data + (size_t)(c->staged ? (c->host_of[slot] >= 0 ? c->host_of[slot] : 0) : slot) * c->b.out_data_stride;
     out->slices = (const venc_slice *)(p + sizeof(venc_out_header));
     out->n_slices = h->n_slices;
     out->total_bytes = h->total_bytes;

@@ -123,9 +123,10 @@ int x264_param_default_preset(x264_param_t *param, const char *preset, const cha
     param->rc.i_qp_constant = 26;
     param->rc.f_rf_constant = 23.0f;
     param->hip.i_device = 0;
-    param->hip.i_gop_batch = 10; /* closed GOPs coded in lock-step (tune zerolatency: 1, below).  A caller shaped like the reference -- a file
-                                    transcoder that drains the encoder through x264_encoder_delayed_frames (av_encode.c:1076) -- wants the
-                                    chip filled, not the first frame early; libx264's own presets delay output by their lookahead too */
+    param->hip.i_gop_batch = 0; /* closed GOPs coded in lock-step: 0 = chosen when the encoder is opened (shim_auto_gop_batch; tune zerolatency: 1,
+                                   below).  A caller shaped like the reference -- a file transcoder that drains the encoder through
+                                   x264_encoder_delayed_frames (av_encode.c:1076) -- wants the chip filled, not the first frame early; libx264's
+                                   own presets delay output by their lookahead too */
     param->hip.i_intra_modes = preset && strcmp(preset, "ultrafast") == 0 ? 2 : 3; /* (libx264: ultrafast analyses no i4x4 partitions) */
     param->hip.i_subpel = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 2;
     param->hip.i_deblock = preset && strcmp(preset, "ultrafast") == 0 ? 0 : 1; /* (libx264: ultrafast sets no-deblock) */
@@ -178,6 +179,28 @@ void x264_picture_clean(x264_picture_t *pic) {
     memset(pic, 0, sizeof(*pic));
 }
 
+/* Closed GOPs advanced in lock-step when the caller left the choice to the encoder (hip.i_gop_batch = 0).  What fills the chip:
+ * the search and the transforms launch items x macroblocks-per-picture lanes -- ten 1080p pictures are 5100 search blocks on 1024
+ * block slots --, but the WAVEFRONT tools (in-loop filter, Intra4x4 trial) launch one block per slice and item and take as long
+ * for 80 blocks as for 256: with either on, items x slices should reach the chip's 256 CUs. */
+static int shim_auto_gop_batch(const x264_param_t *p, int n_slices) {
+    int g = 10;
+    if (p->hip.i_deblock || p->hip.i_intra_modes >= 3) {
+        g = (256 + n_slices - 1) / n_slices;
+        if (g < 10) g = 10;
+    }
+    return g > VENC_MAX_ITEMS ? VENC_MAX_ITEMS : g;
+}
+/* HBM an encoder of gop_batch items takes: per pooled frame (2 x gop_batch x keyint of them) its input picture and its output
+ * staging slot (the conformance bound of 400 bytes per macroblock), per item the engine's rings (reconstructions, levels, records,
+ * entropy buffers: ~22 KB per macroblock) */
+static double shim_device_bytes(int w, int h, int keyint, int gop_batch, int subpel) {
+    const double nmb = (double)((w + 15) / 16) * (double)((h + 15) / 16);
+    const double per_frame = 1.5 * w * h + 400.0 * nmb + 8192.0;
+    const double per_item = nmb * (22.0 * 1024.0 + (subpel ? 3.0 * 256.0 : 0.0));
+    return 2.0 * gop_batch * keyint * per_frame + gop_batch * per_item;
+}
+
 x264_t *x264_encoder_open(x264_param_t *param) {
     if (!param || param->i_width <= 0 || param->i_height <= 0) return NULL;
     x264_t *h = (x264_t *)calloc(1, sizeof(*h));
@@ -189,7 +212,21 @@ x264_t *x264_encoder_open(x264_param_t *param) {
     h->qp = qp;
     h->keyint = param->i_keyint_max > 0 ? param->i_keyint_max : 30;
     h->gop_counter = param->hip.i_gop_base > 0 ? param->hip.i_gop_base : 0;
-    h->gop_batch = param->hip.i_gop_batch > 1 ? param->hip.i_gop_batch : 1;
+    {
+        const int ns = param->i_slice_count > 0 ? param->i_slice_count : 1;
+        h->gop_batch = param->hip.i_gop_batch > 0 ? param->hip.i_gop_batch : param->b_zerolatency ? 1 : shim_auto_gop_batch(param, ns);
+        if (h->gop_batch > VENC_MAX_ITEMS) h->gop_batch = VENC_MAX_ITEMS;
+        /* The unit (gop_batch x keyint frames) is the encoder's delay and half its frame pool: cap it by what the device holds.  Without
+         * this a long keyint -- libx264's own default is 250 -- asked for tens of GB and open or the first upload failed (round 3).
+         * At most half of the device's free memory; never below one GOP at a time. */
+        size_t free_b = 0, total_b = 0;
+        if (h->gop_batch > 1 && venc_device_memory(param->hip.i_device, &free_b, &total_b) == 0 && free_b > 0) {
+            const int asked = h->gop_batch;
+            while (h->gop_batch > 1 && shim_device_bytes(param->i_width, param->i_height, h->keyint, h->gop_batch, param->hip.i_subpel) > 0.5 * (double)free_b) h->gop_batch--;
+            if (h->gop_batch < asked && getenv("VENC_DEBUG"))
+                fprintf(stderr, "x264 [venc]: gop_batch %d -> %d (%.1f GB of device memory free)\n", asked, h->gop_batch, (double)free_b / 1e9);
+        }
+    }
     h->input_depth = param->hip.i_input_depth > 1 ? param->hip.i_input_depth : 1;
     h->enc_trace = getenv("VENC_TRACE") != NULL;
     if (h->gop_batch > VENC_MAX_ITEMS) h->gop_batch = VENC_MAX_ITEMS;
@@ -315,6 +352,8 @@ void x264_encoder_close(x264_t *h) {
 }
 
 int x264_encoder_delayed_frames(x264_t *h) { return h ? (int)(h->n_in - h->n_out) : 0; }
+/* closed GOPs this encoder advances in lock-step (what hip.i_gop_batch = 0 resolved to, after the memory cap) */
+int x264_venc_gop_batch(x264_t *h) { return h ? h->gop_batch : 0; }
 
 /* launch every complete scheduling unit that has not been launched yet;
  * `flush` also launches a trailing partial unit */
@@ -434,6 +473,7 @@ static void *packaging_thread(void *arg) {
         pthread_mutex_unlock(&h->mtx);
         if (stop) break;
         if (assemble_next_unit(h) != 0) {
+            fprintf(stderr, "x264 [venc]: packaging a unit failed: %s\n", venc_last_error()); /* (the reference logs and carries on, av_encode.c:971) */
             pthread_mutex_lock(&h->mtx);
             h->w_err = 1;
             pthread_cond_broadcast(&h->cv_done);
@@ -476,7 +516,12 @@ static int assemble_next_unit(x264_t *h) {
             if (cnt > 0) {
                 shim_frame *f0 = &h->ring[(base + t) % h->pool];
                 if ((h->worker_on ? venc_wait_issued(h->ctx, f0->ticket) : venc_wait(h->ctx, f0->ticket)) != 0) return -1;
-                if (venc_fetch(h->ctx, f0->out_slot, h->keyint, cnt) != 0) return -1;
+                /* (a unit that follows a flushed partial unit does not start on a multiple of the unit and may wrap around the pool: the
+                 * strided fetch goes as far as the slots run on, the frames behind the wrap as a second one) */
+                int run = 0;
+                while (run < cnt && (int64_t)f0->out_slot + (int64_t)run * h->keyint < h->pool) run++;
+                if (venc_fetch(h->ctx, f0->out_slot, h->keyint, run) != 0) return -1;
+                if (run < cnt && venc_fetch(h->ctx, (int)((base + t + (int64_t)run * h->keyint) % h->pool), h->keyint, cnt - run) != 0) return -1;
             }
             for (int g = 0; g < gops; g++) {
                 const int64_t k = (int64_t)g * h->keyint + t;
@@ -513,13 +558,18 @@ static int deliver(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *
     return fr->payload_size;
 }
 
+/* negative returns of the encode call say where they come from when VENC_DEBUG is set (the reference logs and carries on, av_encode.c:971) */
+static int shim_fail(int where) {
+    if (getenv("VENC_DEBUG")) fprintf(stderr, "x264 [venc]: x264_encoder_encode failed at check %d: %s\n", where, venc_last_error());
+    return -1;
+}
 int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_picture_t *pic_in, x264_picture_t *pic_out) {
-    if (!h || !pp_nal || !pi_nal) return -1;
+    if (!h || !pp_nal || !pi_nal) return shim_fail(1);
     *pp_nal = NULL;
     *pi_nal = 0;
     if (pic_in) {
-        if (h->external_input) return -1;
-        if (h->n_in - h->n_out >= h->pool) return -1; /* cannot happen: delay < pool */
+        if (h->external_input) return shim_fail(2);
+        if (h->n_in - h->n_out >= h->pool) return shim_fail(3); /* cannot happen: delay < pool */
         const int64_t f = h->n_in;
         shim_frame *fr = &h->ring[f % h->pool];
         fr->pts = pic_in->i_pts;
@@ -530,17 +580,17 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         const double tt0 = h->enc_trace ? now_ms() : 0;
         if (venc_upload(h->ctx, (int)(f % h->pool), pic_in->img.plane[0], pic_in->img.i_stride[0], pic_in->img.plane[1],
                         pic_in->img.i_stride[1], pic_in->img.plane[2], pic_in->img.i_stride[2]) != 0)
-            return -1;
+            return shim_fail(4);
         const double tt1 = h->enc_trace ? now_ms() : 0;
         /* the caller rewrites pic_in right after this call (av_encode.c:545): wait for the ingest copy -- on its own stream,
          * so this does not wait for the kernels of earlier frames, which keep running beside the copy of the next frame */
         if (h->input_depth > 1) { /* hip.i_input_depth: the picture handed over input_depth - 1 calls ago is the next one the caller fills */
-            if (f >= h->input_depth - 1 && venc_upload_sync_slot(h->ctx, (int)((f - (h->input_depth - 1)) % h->pool)) != 0) return -1;
+            if (f >= h->input_depth - 1 && venc_upload_sync_slot(h->ctx, (int)((f - (h->input_depth - 1)) % h->pool)) != 0) return shim_fail(5);
         } else if (venc_upload_sync(h->ctx) != 0)
-            return -1;
+            return shim_fail(6);
         h->n_in++;
         const double tt2 = h->enc_trace ? now_ms() : 0;
-        if (launch_pending(h, 0) != 0) return -1;
+        if (launch_pending(h, 0) != 0) return shim_fail(7);
         if (h->enc_trace) {
             const double tt3 = now_ms();
             h->enc_ms[0] += tt1 - tt0, h->enc_ms[1] += tt2 - tt1, h->enc_ms[2] += tt3 - tt2, h->enc_ms[4] += 1;
@@ -554,7 +604,7 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
         }
     } else {
         if (h->n_in == h->n_out) return 0;
-        if (launch_pending(h, 1) != 0) return -1;
+        if (launch_pending(h, 1) != 0) return shim_fail(8);
     }
     return deliver(h, pp_nal, pi_nal, pic_out);
 }
