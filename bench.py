@@ -316,12 +316,24 @@ def self_launch(argv, world):
         env["BENCH_LAUNCHED_BY"] = "bench.py self-launch"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for pr in procs:
-        pr.wait()
-        rc = rc or pr.returncode
+    # poll all of them: a rank that exits early with an error leaves its peers blocked in the rendezvous or a barrier until
+    # torch's multi-minute timeout -- end the others at once and report the rank that failed (fresh processes; nothing is re-executed)
+    rc, failed = 0, None
+    live = list(range(world))
+    while live:
+        for r in list(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.remove(r)
+            if code != 0 and rc == 0:
+                rc, failed = code, r
+                for o in live:
+                    procs[o].terminate()
+        if live:
+            time.sleep(0.05)
     if rc:
-        sys.stderr.write("bench: a rank process failed (exit code %d)\n" % rc)
+        sys.stderr.write("bench: rank %d failed (exit code %d); the other ranks were stopped\n" % (failed, rc))
     return 1 if rc else 0
 
 
@@ -688,7 +700,7 @@ def main():
     ap.add_argument("--device", type=int, default=-1, help="force this GPU ordinal for every rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--control", default=None, choices=("nccl", "gloo"), help="torch.distributed backend of the control plane (barrier, max-over-ranks time, the RCCL id); default: --backend")
     ap.add_argument("--no-slices-leg", action="store_true", help="N > 1 streams run: do not measure BASELINE config 5 beside it")
-    ap.add_argument("--slices-timeout", type=int, default=420, help="seconds the slices leg of an N > 1 run may take before it is stopped and reported as an error")
+    ap.add_argument("--slices-timeout", type=int, default=240, help="seconds the slices leg of an N > 1 run may take before it is stopped and reported as an error")
     ap.add_argument("--slices-steps", type=int, default=3, help="timed passes of the slices leg")
     ap.add_argument("--leg-child", action="store_true", help=argparse.SUPPRESS)  # this process is a rank of the slices leg started by slices_leg()
     ap.add_argument("--dry-run", action="store_true", help="launch logic only (rendezvous, barrier, one JSON line): no GPU, gloo; the CPU test of --gpus N")

@@ -888,16 +888,22 @@ def test_reference_open_sequence_at_1080p_chooses_its_items_and_matches_oracle(v
         assert got[t].payload == enc.encode(*f).data, "frame %d" % t
 
 
-def test_long_key_frame_interval_is_capped_by_device_memory_not_a_failed_open(venc):
+def test_long_key_frame_interval_is_capped_by_device_memory_not_a_failed_open(venc, monkeypatch):
     """the unit is gop_batch x keyint frames and the pools twice that; with libx264's own default interval of 250
     at 2160p the preset's 32 items would ask for 400 GB.  x264_encoder_open lowers the items until the pools fit half of the free
-    device memory; the stream still flows: frames in, the same number out through the flush loop, key frames where they belong."""
-    w, h, n = 3840, 2160, 6
+    device memory; the stream still flows: frames in, the same number out through the flush loop, key frames where they belong.
+    (The test narrows the budget to 12 GB -- VENC_POOL_BUDGET_MB -- so that it exercises the cap without holding a hundred GB, whose
+    release slows whatever runs on the device next.)"""
+    monkeypatch.setenv("VENC_POOL_BUDGET_MB", "12000")
+    w, h, n = 1920, 1080, 6
     e = venc.X264Encoder(w, h, fps=(30, 1), sar=(1, 1), preset="medium", tune="film", crf=23, reference_defaults=True, preset_keyint=250)
     assert 1 <= e.gop_batch() < 32, e.gop_batch()
+    out = []
     for t in range(n):
-        assert e.encode(*venc.synth_frame(w, h, t), t) is None
-    out = e.flush()
+        r = e.encode(*venc.synth_frame(w, h, t), t)
+        if r is not None:  # (one item left: the encoder streams, a frame behind)
+            out.append(r)
+    out += e.flush()
     e.close()
     assert len(out) == n and out[0].keyframe and not any(f.keyframe for f in out[1:]) and [f.pts for f in out] == list(range(n))
 

@@ -222,7 +222,9 @@ x264_t *x264_encoder_open(x264_param_t *param) {
         size_t free_b = 0, total_b = 0;
         if (h->gop_batch > 1 && venc_device_memory(param->hip.i_device, &free_b, &total_b) == 0 && free_b > 0) {
             const int asked = h->gop_batch;
-            while (h->gop_batch > 1 && shim_device_bytes(param->i_width, param->i_height, h->keyint, h->gop_batch, param->hip.i_subpel) > 0.5 * (double)free_b) h->gop_batch--;
+            double budget = 0.5 * (double)free_b;
+            if (getenv("VENC_POOL_BUDGET_MB") && atof(getenv("VENC_POOL_BUDGET_MB")) * 1e6 < budget) budget = atof(getenv("VENC_POOL_BUDGET_MB")) * 1e6; /* (tests: the cap without the memory) */
+            while (h->gop_batch > 1 && shim_device_bytes(param->i_width, param->i_height, h->keyint, h->gop_batch, param->hip.i_subpel) > budget) h->gop_batch--;
             if (h->gop_batch < asked && getenv("VENC_DEBUG"))
                 fprintf(stderr, "x264 [venc]: gop_batch %d -> %d (%.1f GB of device memory free)\n", asked, h->gop_batch, (double)free_b / 1e9);
         }
@@ -582,26 +584,28 @@ int x264_encoder_encode(x264_t *h, x264_nal_t **pp_nal, int *pi_nal, x264_pictur
                         pic_in->img.i_stride[1], pic_in->img.plane[2], pic_in->img.i_stride[2]) != 0)
             return shim_fail(4);
         const double tt1 = h->enc_trace ? now_ms() : 0;
+        /* WHILE THE COPY FLIES (round 4): the unit's kernel launches, if this picture completes one (they wait for the pictures' copy
+         * events on the GPU), and the hand-over of the output frame that is due.  Round 3 waited for the copy first and did both
+         * behind it: ~6 us of every ~81 us call with the reference's one pic_in, whose copy (71.6 us alone at 1080p) cannot start
+         * before the call and must end before it returns. */
+        h->n_in++;
+        int ret = 0;
+        if (launch_pending(h, 0) != 0) ret = shim_fail(7);
+        const double tt2 = h->enc_trace ? now_ms() : 0;
+        if (ret == 0 && h->n_in - h->n_out > h->delay) ret = deliver(h, pp_nal, pi_nal, pic_out);
+        const double tt3 = h->enc_trace ? now_ms() : 0;
         /* the caller rewrites pic_in right after this call (av_encode.c:545): wait for the ingest copy -- on its own stream,
-         * so this does not wait for the kernels of earlier frames, which keep running beside the copy of the next frame */
+         * so this does not wait for the kernels of earlier frames, which keep running beside the copy of the next frame.  On every
+         * path, also a failed one: the picture must not change under a copy in flight. */
         if (h->input_depth > 1) { /* hip.i_input_depth: the picture handed over input_depth - 1 calls ago is the next one the caller fills */
             if (f >= h->input_depth - 1 && venc_upload_sync_slot(h->ctx, (int)((f - (h->input_depth - 1)) % h->pool)) != 0) return shim_fail(5);
         } else if (venc_upload_sync(h->ctx) != 0)
             return shim_fail(6);
-        h->n_in++;
-        const double tt2 = h->enc_trace ? now_ms() : 0;
-        if (launch_pending(h, 0) != 0) return shim_fail(7);
-        if (h->enc_trace) {
-            const double tt3 = now_ms();
-            h->enc_ms[0] += tt1 - tt0, h->enc_ms[1] += tt2 - tt1, h->enc_ms[2] += tt3 - tt2, h->enc_ms[4] += 1;
-        }
-        if (h->n_in - h->n_out <= h->delay) return 0;
         if (h->enc_trace) {
             const double tt4 = now_ms();
-            const int r = deliver(h, pp_nal, pi_nal, pic_out);
-            h->enc_ms[3] += now_ms() - tt4;
-            return r;
+            h->enc_ms[0] += tt1 - tt0, h->enc_ms[1] += tt4 - tt3, h->enc_ms[2] += tt2 - tt1, h->enc_ms[3] += tt3 - tt2, h->enc_ms[4] += 1;
         }
+        return ret;
     } else {
         if (h->n_in == h->n_out) return 0;
         if (launch_pending(h, 1) != 0) return shim_fail(8);
