@@ -70,7 +70,7 @@ DEVFN uint32_t nc_bytes4(uint32_t A, uint32_t Bv, uint32_t mA, uint32_t mB) {
  * An entry's string leaves as ONE 16-byte store (venc_bitsink4: four words in registers; the rare entry beyond 128 bits spills
  * into the macroblock's region of mbbits and says so in ent_list).
  * Dynamic LDS: 36 bytes per lane (the 16 levels of the block being coded + a dword against bank conflicts), 2 bytes x ENT_LEN_LDS
- * (lengths), 4 bytes x ENT_CLS_LDS (the list of phase B); longer segments continue in memory. */
+ * (lengths), 8 bytes x ENT_CLS_LDS (the list of phase B: record + the empty blocks behind the entry); longer segments continue in memory. */
 #ifndef ENT_CLS_LDS
 #define ENT_CLS_LDS 1024 /* entries of phase B's list kept in LDS */
 #endif
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     if (j * ENT_SEG_MBS >= last - first) return;
     lds_u32 *strip = (lds_u32 *)(s_dyn + tid * 9); /* (written as dwords, read by the coder as int16: may_alias, see venc_kernels.hip) */
     uint16_t *s_len = (uint16_t *)(s_dyn + ENT_THREADS * 9);
-    uint32_t *s_cls = s_dyn + ENT_THREADS * 9 + ENT_LEN_LDS / 2;
+    uint32_t *s_cls = s_dyn + ENT_THREADS * 9 + ENT_LEN_LDS / 2, *s_cls2 = s_cls + ENT_CLS_LDS; /* (s_cls2: the empty blocks behind a listed block) */
     const int mb_seg = first + j * ENT_SEG_MBS;
     const int mb = mb_seg + tid;
     const bool in = mb < last;
@@ -143,7 +143,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         }
     }
     /* ranks (bitstream order) and the places in phase B's list: one block scan of three counts */
-    const uint32_t n_all = (uint32_t)__popc(em), n_n = (uint32_t)__popc(nm), n_r = em & 1u;
+    /* entries: R, H and the blocks with levels; the coeff_tokens of the blocks WITHOUT a level ride at the end of the entry before
+     * them (at most three behind an H, seven behind a block: a coded 8x8 block or a coded chroma AC plane holds a block with levels) */
+    const uint32_t n_all = (uint32_t)__popc(em & (3u | nm)), n_n = (uint32_t)__popc(nm), n_r = em & 1u;
     const uint32_t ia = wave_scan_incl(n_all | (n_n << 16)), ir = wave_scan_incl(n_r);
     if (lane == 63) s_wa[tid >> 6] = ia, s_wr[tid >> 6] = ir;
     /* the first wave: P_Skip macroblocks directly before the segment (the run a mb_skip_run of this segment may continue) */
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     const size_t seg = ent_seg(g, B, v, s, j);
     const uint32_t count = ta & 0xffffu, n_r_all = tr, n_rn = tr + (ta >> 16);
     uint4 *head = B.ent_head + seg * B.ent_cap;
-    uint32_t *cls_mem = B.ent_cls + seg * B.ent_cap, *list = B.ent_list + seg * B.ent_cap;
+    uint32_t *cls_mem = B.ent_cls + seg * B.ent_cap, *cls2_mem = B.ent_cls2 + seg * B.ent_cap, *list = B.ent_list + seg * B.ent_cap;
     uint16_t *len_mem = (uint16_t *)(B.ent_off + seg * (B.ent_cap + 4)) + 2 * (B.ent_cap + 4) - B.ent_cap - 8; /* (lengths beyond the LDS part park in the upper half of the segment's
                                                                                                                   offsets, which phase C fills from below: rank k's offset is written after every length <= k was read) */
     if (in) B.ent_mb0[(size_t)v * g.nmb + mb] = (xa & 0xffffu) | (n_all << 16); /* (debug / tests: the macroblock's entries are ranks [lo, lo + hi)) */
@@ -203,6 +205,29 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             for (int pl = 0; pl < 2; pl++)
                 ncc[pl] = nc_bytes4(__builtin_amdgcn_perm(oc[pl], lc[pl], 0x06030401u), __builtin_amdgcn_alignbyte(oc[pl], tc[pl], 2u), mLc, mTc);
         }
+        /* `tail`: the empty blocks since the last entry, two bits each (their coeff_token's nC class) from bit 0, the count in bits
+         * 16-18.  It is flushed into the entry before them when the next block with levels (or the macroblock's end) comes: appended
+         * to the H string here, handed to phase B beside the block's list record (s_cls2) */
+        uint32_t tail = 0, prev_pos = 0;
+        int prev_kind = 0; /* 0 none / R (never followed by empty blocks), 1 H (string open in hbs), 2 block with levels at list place prev_pos */
+        venc_bitsink4 hbs;
+        venc_bs4_init(&hbs, nullptr);
+        uint32_t h_rank = 0;
+/* (a macro, not a lambda: through a closure the sink's registers were spilled, 192 bytes of scratch per lane) */
+#define ENT_FLUSH_TAIL()                                                                                                                        \
+    do {                                                                                                                                        \
+        if (prev_kind == 1) {                                                                                                                   \
+            for (uint32_t t_ = tail, n_ = tail >> 16; n_; n_--, t_ >>= 2) {                                                                     \
+                const uint32_t c_ = t_ & 3u; /* coeff_token of TotalCoeff 0 (table 9-5): 1, 11, 1111, 0000 11 for nC < 2, < 4, < 8, >= 8 */     \
+                venc_bs_put(&hbs, c_ == 3u ? 3u : (1u << (c_ == 0u ? 1 : c_ == 1u ? 2 : 4)) - 1u, c_ == 0u ? 1 : c_ == 1u ? 2 : c_ == 2u ? 4 : 6); \
+            }                                                                                                                                   \
+            ENT_LEN_PUT(h_rank, venc_bs_flush(&hbs));                                                                                           \
+            head[h_rank] = make_uint4(hbs.h0, hbs.h1, hbs.h2, hbs.h3);                                                                          \
+        } else if (prev_kind == 2) {                                                                                                            \
+            if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;                                                \
+        }                                                                                                                                       \
+        tail = 0;                                                                                                                               \
+    } while (0)
         while (em) {
             const int slot = __builtin_ctz(em);
             em &= em - 1u;
@@ -210,17 +235,16 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                 const uint32_t rec = (rank << 18) | ((uint32_t)tid << 5);
                 if (pos_r < ENT_CLS_LDS) s_cls[pos_r] = rec; else cls_mem[pos_r] = rec;
                 pos_r++;
+                rank++;
             } else if (slot == 1) {
-                /* mb_type P_L0_16x16, mvd_l0 in quarter samples, coded_block_pattern, mb_qp_delta: at most 49 bits */
-                venc_bitsink4 bs;
-                venc_bs4_init(&bs, nullptr);
-                venc_bs_ue(&bs, 0u);
-                venc_bs_se(&bs, (dx - pxv) << (g.subpel ? 0 : 2));
-                venc_bs_se(&bs, (dy - pyv) << (g.subpel ? 0 : 2));
-                venc_bs_ue(&bs, venc_cbp_inter_code[cbp]);
-                if (cbp) venc_bs_se(&bs, 0);
-                ENT_LEN_PUT(rank, venc_bs_flush(&bs));
-                head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
+                /* mb_type P_L0_16x16, mvd_l0 in quarter samples, coded_block_pattern, mb_qp_delta: at most 49 bits (+ 18 of empty blocks) */
+                venc_bs_ue(&hbs, 0u);
+                venc_bs_se(&hbs, (dx - pxv) << (g.subpel ? 0 : 2));
+                venc_bs_se(&hbs, (dy - pyv) << (g.subpel ? 0 : 2));
+                venc_bs_ue(&hbs, venc_cbp_inter_code[cbp]);
+                if (cbp) venc_bs_se(&hbs, 0);
+                h_rank = rank++;
+                prev_kind = 1;
             } else {
                 uint32_t nC;
                 if (slot < 18) {
@@ -230,17 +254,19 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                 } else
                     nC = slot < 20 ? 0u : ((slot < 24 ? ncc[0] : ncc[1]) >> (8 * ((slot - 20) & 3))) & 255u;
                 if ((nm >> slot) & 1u) {
+                    ENT_FLUSH_TAIL();
                     const uint32_t rec = (rank << 18) | ((slot == 18 || slot == 19 ? 0u : nC + 1u) << 13) | ((uint32_t)tid << 5) | (uint32_t)slot;
                     if (pos_n < ENT_CLS_LDS) s_cls[pos_n] = rec; else cls_mem[pos_n] = rec;
-                    pos_n++;
-                } else { /* coeff_token of TotalCoeff 0 (table 9-5): 1, 11, 1111, 0000 11 for nC < 2, < 4, < 8, >= 8 */
-                    const uint32_t len = nC < 2u ? 1u : nC < 4u ? 2u : nC < 8u ? 4u : 6u;
-                    ENT_LEN_PUT(rank, len);
-                    head[rank] = make_uint4((nC < 8u ? 0xffffffffu : 0x0c000000u) << (nC < 8u ? 32u - len : 0u), 0u, 0u, 0u);
+                    prev_pos = pos_n++;
+                    prev_kind = 2;
+                    rank++;
+                } else {
+                    const uint32_t n = tail >> 16;
+                    tail = (tail & 0xffffu) | ((nC < 2u ? 0u : nC < 4u ? 1u : nC < 8u ? 2u : 3u) << (2u * n)) | ((n + 1u) << 16);
                 }
             }
-            rank++;
         }
+        ENT_FLUSH_TAIL();
     }
     __syncthreads();
     /* ---------------------------------------------------------------- phase B */
@@ -299,6 +325,10 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         venc_bitsink4 bs;
         venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mbk) * VENC_MB_WORDS + slot * VENC_LANE_WORDS);
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, firstc, maxc, nC, s_tab);
+        for (uint32_t t = k < ENT_CLS_LDS ? s_cls2[k] : cls2_mem[k], n = t >> 16; n; n--, t >>= 2) { /* the empty blocks behind it */
+            const uint32_t c = t & 3u;
+            venc_bs_put(&bs, c == 3u ? 3u : (1u << (c == 0u ? 1 : c == 1u ? 2 : 4)) - 1u, c == 0u ? 1 : c == 1u ? 2 : c == 2u ? 4 : 6);
+        }
         const int bits = venc_bs_flush(&bs);
         ENT_LEN_PUT(rank, bits);
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);

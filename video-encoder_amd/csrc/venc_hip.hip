@@ -355,6 +355,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipFree(c->b.codedmask);
     (void)hipFree(c->b.ent_list);
     (void)hipFree(c->b.ent_cls);
+    (void)hipFree(c->b.ent_cls2);
     (void)hipFree(c->b.ent_mb0);
     (void)hipFree(c->b.ent_count);
     (void)hipFree(c->b.ent_head);
@@ -646,6 +647,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         OPEN_OK(hipMalloc(&b.codedmask, GV * g.n_slices * b.ent_wps * 8));
         OPEN_OK(hipMalloc(&b.ent_list, nseg * b.ent_cap * 4));
         OPEN_OK(hipMalloc(&b.ent_cls, nseg * b.ent_cap * 4));
+        OPEN_OK(hipMalloc(&b.ent_cls2, nseg * b.ent_cap * 4));
         OPEN_OK(hipMalloc(&b.ent_mb0, GV * nmb * 4));
         OPEN_OK(hipMalloc(&b.ent_count, nseg * 16));
         OPEN_OK(hipMemset(b.ent_count, 0, nseg * 16));
@@ -1304,7 +1306,7 @@ static int entropy_flush(venc_ctx *c) {
     else {
         /* P pictures (venc_cavlc_p.hip): one block per segment of 256 macroblocks of a slice in both kernels */
         const dim3 eg(c->b.ent_spp, band_slices, nv);
-        hipLaunchKernelGGL(k_entropy_p, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (size_t)ENT_LEN_LDS * 2 + (size_t)ENT_CLS_LDS * 4, s2, g, b, S);
+        hipLaunchKernelGGL(k_entropy_p, eg, dim3(ENT_THREADS), (size_t)ENT_THREADS * 36 + (size_t)ENT_LEN_LDS * 2 + (size_t)ENT_CLS_LDS * 8, s2, g, b, S);
     }
     prof_end(c, s2);
     if (c->overlap) {

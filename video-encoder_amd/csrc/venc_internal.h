@@ -117,6 +117,7 @@ typedef struct {
     unsigned long long *codedmask; /* [G][n_slices][ent_wps] bit = macroblock (slice-relative index) is coded (not P_Skip), k_skip2 */
     uint32_t *ent_list;         /* [segments][ent_cap] mb << 5 | slot of the entries whose strings run beyond 128 bits (the others: not written) */
     uint32_t *ent_cls;          /* [segments][ent_cap] phase B's list of k_entropy_p beyond what its LDS holds */
+    uint32_t *ent_cls2;         /* [segments][ent_cap] ... and the empty blocks behind those entries (two bits of nC class each, count << 16) */
     uint32_t *ent_count;        /* [segments] entries */
     uint32_t *ent_mb0;          /* [G][nmb] rank of the macroblock's first entry | its entries << 16 (debug / tests) */
     uint4 *ent_head;            /* [segments][ent_cap] */
