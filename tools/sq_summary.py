@@ -34,7 +34,7 @@ names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "
 print("%-14s %8s %9s %8s  " % ("kernel", "avg_us", "valu_util", "lds_busy") + " ".join("%20s" % n for n in names))
 VALU_ISSUE_CYCLES = 4.3  # measured cost of one wave-instruction on a SIMD with >= 2 waves (tools/valu_ubench.hip: 4.2-4.5 for all but four opcodes)
 doc_k = {}
-for k in ("k_me_pool", "k_me_fix", "k_inter_fused", "k_skip", "k_cavlc_p", "k_scan", "k_pack", "k_intra_fwd", "k_intra_dc", "k_intra_rec", "k_cavlc"):
+for k in ("k_me_pool", "k_me_fix", "k_inter_fused", "k_entropy_p", "k_pack_p", "k_scan", "k_pack", "k_intra_fwd", "k_intra_dc", "k_intra_rec", "k_cavlc"):
     if not dur[k][1]:
         continue
     us = dur[k][0] / dur[k][1]

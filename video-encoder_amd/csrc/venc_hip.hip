@@ -168,6 +168,7 @@ struct venc_ctx {
      * 1.96 GB for the preset's 600 slots at 1080p, 7.8 GB at 2160p, tens of GB for a long keyint) where 40 buffers do.  A frame's bytes
      * stay valid on the host until host_slots further frames have been fetched.  Only venc_fetch / venc_get_frame touch these
      * (one thread: the packaging thread, or the caller's in engines without one). */
+    size_t lds_per_block; /* hipDeviceProp_t.sharedMemPerBlock */
     int host_slots;       /* buffers in h_data (direct engines: out_slots, slot = buffer) */
     int *host_of;         /* [out_slots] buffer that holds the slot's bytes (-1: none) */
     int *host_owner;      /* [host_slots] slot whose bytes the buffer holds (-1: none) */
@@ -261,7 +262,10 @@ static void launch_deblock(venc_ctx *c, hipStream_t st, const venc_geom &g, cons
     if (strip)
         hipLaunchKernelGGL(k_deblock, dim3(S.slice1 - S.slice0, 1, n_items), dim3(64 * waves), (size_t)waves * sizeof(dbk_strip), st, g, b, S, planes);
     else {
-        const int lw = (max_rows + 3) / 4 < DL_MAX_WAVES / 2 ? (max_rows + 3) / 4 : DL_MAX_WAVES / 2; /* filter waves; as many helper waves */
+        int lw = (max_rows + 3) / 4 < DL_MAX_WAVES / 2 ? (max_rows + 3) / 4 : DL_MAX_WAVES / 2; /* filter waves; as many helper waves */
+        /* (4 x lw row rings of 2288 bytes: eight filter waves take 73 KB, which a gfx950 CU has (160 KB) and a 64 KB part has not; the kernel
+         * runs taller slices in passes anyway, so fewer rows at a time is only slower -- never a launch that silently does not happen) */
+        while (lw > 1 && (size_t)4 * lw * sizeof(dl_row) > c->lds_per_block) lw--;
         const dim3 grid(S.slice1 - S.slice0, 1, n_items), block(2 * 64 * lw);
         const size_t lds = (size_t)4 * lw * sizeof(dl_row);
         static const int diag = getenv("VENC_DL_DIAG") ? atoi(getenv("VENC_DL_DIAG")) : 0; /* (diagnostic: parts of a step left out, pictures then wrong) */
@@ -486,6 +490,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         const int ncu = e ? atoi(e) : step_mbs >= 200000 ? 160 : step_mbs >= 60000 ? 192 : 0;
         hipDeviceProp_t prop;
         OPEN_OK(hipGetDeviceProperties(&prop, cfg->device));
+        c->lds_per_block = prop.sharedMemPerBlock;
         if (ncu >= 8 && ncu < prop.multiProcessorCount) {
             uint32_t mask[16] = {0};
             for (int i = 0; i < ncu && i < 512; i++) mask[i >> 5] |= 1u << (i & 31);
