@@ -101,7 +101,8 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     const int mb = mb_seg + tid;
     const bool in = mb < last;
     const int mbc = in ? mb : first;
-    const int my = mbc / g.mbw, mx = mbc - my * g.mbw;
+    int mx, my;
+    mb_xy(g, mbc, mx, my);
     const bool aL = mx > 0, aT = my > srow;
     const venc_mbinfo *infos = B.mbinfo + (size_t)v * g.nmb;
     const uint32_t *mvs = B.mvsad + (size_t)v * g.nmb;
@@ -157,7 +158,8 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                 const int idx = base - 1 - lane;
                 const bool valid = idx >= first;
                 const int ic = valid ? idx : first;
-                const int iy = ic / g.mbw, ix = ic - iy * g.mbw;
+                int ix, iy;
+                mb_xy(g, ic, ix, iy);
                 const uint32_t rec = ((const uint32_t *)(infos + ic))[6];
                 const bool sk = mb_is_p_skip(g, mvs, ic, ix, ix > 0, iy > srow, (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4));
                 const unsigned long long cb = __ballot(valid && !sk), vb = __ballot(valid);
@@ -205,68 +207,76 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             for (int pl = 0; pl < 2; pl++)
                 ncc[pl] = nc_bytes4(__builtin_amdgcn_perm(oc[pl], lc[pl], 0x06030401u), __builtin_amdgcn_alignbyte(oc[pl], tc[pl], 2u), mLc, mTc);
         }
-        /* `tail`: the empty blocks since the last entry, two bits each (their coeff_token's nC class) from bit 0, the count in bits
-         * 16-18.  It is flushed into the entry before them when the next block with levels (or the macroblock's end) comes: appended
-         * to the H string here, handed to phase B beside the block's list record (s_cls2) */
-        uint32_t tail = 0, prev_pos = 0;
-        int prev_kind = 0; /* 0 none / R (never followed by empty blocks), 1 H (string open in hbs), 2 block with levels at list place prev_pos */
-        venc_bitsink4 hbs;
-        venc_bs4_init(&hbs, nullptr);
-        uint32_t h_rank = 0;
-/* (a macro, not a lambda: through a closure the sink's registers were spilled, 192 bytes of scratch per lane) */
-#define ENT_FLUSH_TAIL()                                                                                                                        \
-    do {                                                                                                                                        \
-        if (prev_kind == 1) {                                                                                                                   \
-            for (uint32_t t_ = tail, n_ = tail >> 16; n_; n_--, t_ >>= 2) {                                                                     \
-                const uint32_t c_ = t_ & 3u; /* coeff_token of TotalCoeff 0 (table 9-5): 1, 11, 1111, 0000 11 for nC < 2, < 4, < 8, >= 8 */     \
-                venc_bs_put(&hbs, c_ == 3u ? 3u : (1u << (c_ == 0u ? 1 : c_ == 1u ? 2 : 4)) - 1u, c_ == 0u ? 1 : c_ == 1u ? 2 : c_ == 2u ? 4 : 6); \
-            }                                                                                                                                   \
-            ENT_LEN_PUT(h_rank, venc_bs_flush(&hbs));                                                                                           \
-            head[h_rank] = make_uint4(hbs.h0, hbs.h1, hbs.h2, hbs.h3);                                                                          \
-        } else if (prev_kind == 2) {                                                                                                            \
-            if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;                                                \
-        }                                                                                                                                       \
-        tail = 0;                                                                                                                               \
-    } while (0)
-        while (em) {
-            const int slot = __builtin_ctz(em);
-            em &= em - 1u;
-            if (slot == 0) {
-                const uint32_t rec = (rank << 18) | ((uint32_t)tid << 5);
-                if (pos_r < ENT_CLS_LDS) s_cls[pos_r] = rec; else cls_mem[pos_r] = rec;
-                pos_r++;
-                rank++;
-            } else if (slot == 1) {
-                /* mb_type P_L0_16x16, mvd_l0 in quarter samples, coded_block_pattern, mb_qp_delta: at most 49 bits (+ 18 of empty blocks) */
-                venc_bs_ue(&hbs, 0u);
-                venc_bs_se(&hbs, (dx - pxv) << (g.subpel ? 0 : 2));
-                venc_bs_se(&hbs, (dy - pyv) << (g.subpel ? 0 : 2));
-                venc_bs_ue(&hbs, venc_cbp_inter_code[cbp]);
-                if (cbp) venc_bs_se(&hbs, 0);
-                h_rank = rank++;
-                prev_kind = 1;
-            } else {
-                uint32_t nC;
-                if (slot < 18) {
-                    const int bk = slot - 2, by = blk_y(bk), bx = blk_x(bk);
-                    const uint32_t wd = by == 0 ? ncl[0] : by == 1 ? ncl[1] : by == 2 ? ncl[2] : ncl[3];
-                    nC = (wd >> (8 * bx)) & 255u;
-                } else
-                    nC = slot < 20 ? 0u : ((slot < 24 ? ncc[0] : ncc[1]) >> (8 * ((slot - 20) & 3))) & 255u;
-                if ((nm >> slot) & 1u) {
-                    ENT_FLUSH_TAIL();
-                    const uint32_t rec = (rank << 18) | ((slot == 18 || slot == 19 ? 0u : nC + 1u) << 13) | ((uint32_t)tid << 5) | (uint32_t)slot;
-                    if (pos_n < ENT_CLS_LDS) s_cls[pos_n] = rec; else cls_mem[pos_n] = rec;
-                    prev_pos = pos_n++;
-                    prev_kind = 2;
-                    rank++;
-                } else {
-                    const uint32_t n = tail >> 16;
-                    tail = (tail & 0xffffu) | ((nC < 2u ? 0u : nC < 4u ? 1u : nC < 8u ? 2u : 3u) << (2u * n)) | ((n + 1u) << 16);
+        /* The nC CLASS of every block (what selects its coeff_token table: nC < 2, < 4, < 8, >= 8), two bits per block in slot order
+         * (block b = slot 2 + b at bits 2 b): classified four bytes at a time (n >= k  <=>  bit 7 of n + 128 - k; n <= 16), then put
+         * into luma4x4BlkIdx order.  A block with levels takes its table from it (phase B needs no count), an empty block its token. */
+        unsigned long long cw;
+        {
+            uint32_t c4[6];
+            const uint32_t ncw[6] = {ncl[0], ncl[1], ncl[2], ncl[3], ncc[0], ncc[1]};
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                c4[i] = (((ncw[i] + 0x7e7e7e7eu) >> 7) & 0x01010101u) + (((ncw[i] + 0x7c7c7c7cu) >> 7) & 0x01010101u) + (((ncw[i] + 0x78787878u) >> 7) & 0x01010101u);
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int bk = 0; bk < 16; bk++) lo |= ((c4[blk_y(bk)] >> (8 * blk_x(bk))) & 3u) << (2 * bk);
+#pragma unroll
+            for (int k = 0; k < 8; k++) hi |= ((c4[4 + (k >> 2)] >> (8 * (k & 3))) & 3u) << (4 + 2 * k); /* (blocks 16, 17 = the chroma DC blocks: no class) */
+            cw = ((unsigned long long)hi << 32) | lo;
+        }
+#define ENT_TOKEN0(sink, c_) venc_bs_put(sink, (c_) == 3u ? 3u : (1u << ((c_) == 0u ? 1 : (c_) == 1u ? 2 : 4)) - 1u, (c_) == 0u ? 1 : (c_) == 1u ? 2 : (c_) == 2u ? 4 : 6) /* coeff_token of TotalCoeff 0 (table 9-5): 1, 11, 1111, 0000 11 */
+        if (em & 1u) { /* R: left to phase B */
+            const uint32_t rec = (rank << 18) | ((uint32_t)tid << 5);
+            if (pos_r < ENT_CLS_LDS) s_cls[pos_r] = rec; else cls_mem[pos_r] = rec;
+            rank++;
+        }
+        uint32_t blocks = em >> 2; /* bit b = block b (slot 2 + b) is an entry or rides on one */
+        const uint32_t lev = nm >> 2; /* ... and holds levels */
+        if (em & 2u) {
+            /* H: mb_type P_L0_16x16, mvd_l0 in quarter samples, coded_block_pattern, mb_qp_delta (at most 49 bits), then the tokens of the
+             * empty blocks in front of the first block with levels (at most three: 18 bits) */
+            venc_bitsink4 hbs;
+            venc_bs4_init(&hbs, nullptr);
+            venc_bs_ue(&hbs, 0u);
+            venc_bs_se(&hbs, (dx - pxv) << (g.subpel ? 0 : 2));
+            venc_bs_se(&hbs, (dy - pyv) << (g.subpel ? 0 : 2));
+            venc_bs_ue(&hbs, venc_cbp_inter_code[cbp]);
+            if (cbp) venc_bs_se(&hbs, 0);
+            uint32_t lead = lev ? blocks & ((1u << __builtin_ctz(lev)) - 1u) : blocks;
+            blocks &= ~lead;
+            while (lead) {
+                const int bq = __builtin_ctz(lead);
+                lead &= lead - 1u;
+                ENT_TOKEN0(&hbs, (uint32_t)(cw >> (2 * bq)) & 3u);
+            }
+            ENT_LEN_PUT(rank, venc_bs_flush(&hbs));
+            head[rank] = make_uint4(hbs.h0, hbs.h1, hbs.h2, hbs.h3);
+            rank++;
+        }
+        /* the blocks: one with levels is listed for phase B (its table class beside it); the empty ones behind it ride on it: `tail` = their
+         * classes, two bits each from bit 0, the count in bits 16-18 (at most seven: a coded 8x8 block / chroma AC plane holds levels) */
+        uint32_t tail = 0, prev_pos = 0xffffffffu;
+        while (blocks) {
+            const int bq = __builtin_ctz(blocks);
+            blocks &= blocks - 1u;
+            const uint32_t c = (uint32_t)(cw >> (2 * bq)) & 3u;
+            if ((lev >> bq) & 1u) {
+                if (prev_pos != 0xffffffffu) {
+                    if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;
                 }
+                tail = 0;
+                const uint32_t rec = (rank << 18) | ((bq == 16 || bq == 17 ? 0u : 1u + (c == 0u ? 0u : c == 1u ? 2u : c == 2u ? 4u : 8u)) << 13) | ((uint32_t)tid << 5) | (uint32_t)(bq + 2);
+                if (pos_n < ENT_CLS_LDS) s_cls[pos_n] = rec; else cls_mem[pos_n] = rec;
+                prev_pos = pos_n++;
+                rank++;
+            } else {
+                const uint32_t n = tail >> 16;
+                tail = (tail & 0xffffu) | (c << (2u * n)) | ((n + 1u) << 16);
             }
         }
-        ENT_FLUSH_TAIL();
+        if (prev_pos != 0xffffffffu) {
+            if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;
+        }
     }
     __syncthreads();
     /* ---------------------------------------------------------------- phase B */
@@ -325,10 +335,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         venc_bitsink4 bs;
         venc_bs4_init(&bs, B.mbbits + ((size_t)v * g.nmb + mbk) * VENC_MB_WORDS + slot * VENC_LANE_WORDS);
         venc_cavlc_block_mem(&bs, (const int16_t *)strip, nz, firstc, maxc, nC, s_tab);
-        for (uint32_t t = k < ENT_CLS_LDS ? s_cls2[k] : cls2_mem[k], n = t >> 16; n; n--, t >>= 2) { /* the empty blocks behind it */
-            const uint32_t c = t & 3u;
-            venc_bs_put(&bs, c == 3u ? 3u : (1u << (c == 0u ? 1 : c == 1u ? 2 : 4)) - 1u, c == 0u ? 1 : c == 1u ? 2 : c == 2u ? 4 : 6);
-        }
+        for (uint32_t t = k < ENT_CLS_LDS ? s_cls2[k] : cls2_mem[k], n = t >> 16; n; n--, t >>= 2) ENT_TOKEN0(&bs, t & 3u); /* the empty blocks behind it */
         const int bits = venc_bs_flush(&bs);
         ENT_LEN_PUT(rank, bits);
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);

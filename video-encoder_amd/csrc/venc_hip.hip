@@ -445,6 +445,7 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     g.cw = g.mbw * 16;
     g.ch = g.mbh * 16;
     g.nmb = g.mbw * g.mbh;
+    g.mbw_magic = g.mbw > 1 ? (uint32_t)((0x100000000ull + (uint64_t)g.mbw - 1) / (uint64_t)g.mbw) : 0u;
     g.n_slices = cfg->n_slices < 1 ? 1 : cfg->n_slices;
     if (g.n_slices > g.mbh) g.n_slices = g.mbh;
     if (g.n_slices > VENC_MAX_SLICES) g.n_slices = VENC_MAX_SLICES;

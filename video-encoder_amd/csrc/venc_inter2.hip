@@ -337,7 +337,8 @@ struct chroma_listed { /* a chroma block that holds an AC level, between the two
 DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, int lane, int mb, bool valid, int dx, int dy,
                            const venc_qparams &qc, chroma_listed *cl, uint32_t *cl_count) {
     const int k = lane & 3, plane = 1 + ((lane >> 2) & 1), qbase = lane & ~3, gbase = lane & 56;
-    const int mx = mb % g.mbw, my = mb / g.mbw;
+    int mx, my;
+    mb_xy(g, mb, mx, my);
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
     int cstride, pw, ph, rstride, wstride;
     const uint8_t *cur = in_plane(B, g, S.in_slot[item], plane, cstride, pw, ph);
@@ -479,7 +480,8 @@ DEVFN void inter_chroma_mb(const venc_geom &g, const venc_bufs &B, const venc_st
 /* one listed chroma block, any lane: residual ... reconstruction, its levels and its count */
 DEVFN void inter_chroma_listed(const venc_geom &g, const venc_bufs &B, const venc_step &S, int item, const chroma_listed &e, const venc_qparams &qc) {
     const int mb = (int)(e.id >> 3), pk = (int)(e.id & 7u), plane = 1 + (pk >> 2), k = pk & 3;
-    const int my = mb / g.mbw, mx = mb - my * g.mbw;
+    int mx, my;
+    mb_xy(g, mb, mx, my);
     const int px = mx * 8 + (k & 1) * 4, py = my * 8 + (k >> 1) * 4;
     int wstride;
     uint8_t *rec = rec_plane(B, g, S.parity, item, plane, wstride);

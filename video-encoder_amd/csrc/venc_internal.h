@@ -59,6 +59,7 @@ typedef struct {
     int w, h;        /* display */
     int cw, ch;      /* coded */
     int mbw, mbh, nmb;
+    uint32_t mbw_magic; /* ceil(2^32 / mbw): mb / mbw = umulhi(mb, magic), exact while mb x mbw < 2^32 (0 stands for mbw = 1) */
     int n_slices;
     int slice_base, slice_rem; /* bands: the first slice_rem slices have slice_base+1 MB rows, the rest slice_base */
     int qp;

@@ -51,6 +51,11 @@ DEVFN uint8_t *rec_plane(const venc_bufs &B, const venc_geom &g, int parity, int
     return base + ysz + (plane == 2 ? (ysz >> 2) : 0);
 }
 DEVFN int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+/* macroblock address -> (column, row) without an integer division (~25 instructions): one high multiply by ceil(2^32 / mbw) */
+DEVFN void mb_xy(const venc_geom &g, int mb, int &mx, int &my) {
+    my = g.mbw_magic ? (int)__umulhi((uint32_t)mb, g.mbw_magic) : mb;
+    mx = mb - my * g.mbw;
+}
 /* first MB row of the slice that contains MB row my (bands are uniform: no table lookup, no memory round trip) */
 DEVFN int slice_first_row_of(const venc_geom &g, int my) {
     const int big = g.slice_rem * (g.slice_base + 1);
