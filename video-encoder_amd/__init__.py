@@ -464,7 +464,7 @@ class Engine:
                   3: ((self.nmb,), np.uint32), 4: ((ch, cw), np.uint8), 5: ((ch // 2, cw // 2), np.uint8),
                   6: ((ch // 2, cw // 2), np.uint8), 7: ((self.nmb,), np.uint32),
                   8: ((ch + 25, (cw + 32) & ~15), np.uint32), 9: ((self.nmb,), np.uint8), 10: ((self.nmb,), np.uint8),
-                  11: ((8,), np.uint64), 12: ((self.nmb, 32), np.int32), 13: ((self.nmb, 128), np.int32),
+                  11: ((8 + 2 * 16384,), np.uint64), 12: ((self.nmb, 32), np.int32), 13: ((self.nmb, 128), np.int32),
                   14: ((self.nmb,), np.uint32), 15: ((3, ch, cw), np.uint8)}
         shape, dt = shapes[what]
         a = np.empty(shape, dt)

@@ -55,6 +55,25 @@ DEVFN uint32_t nc_bytes4(uint32_t A, uint32_t Bv, uint32_t mA, uint32_t mB) {
     return (both & mA & mB) | (A & mA & ~mB) | (Bv & ~mA & mB);
 }
 
+/* P_Skip (7.3.4, 8.4.1.1, 8.4.1.3.1) from values already loaded: the macroblock's vector, its neighbours' A (left), B (top), and C (top
+ * right, or D top left when C is missing) -- what mb_is_p_skip (venc_kernels.hip) decides with loads that depend on one another */
+DEVFN bool p_skip_vals(const venc_geom &g, int mx, bool aL, bool aT, int cbp, uint32_t me, uint32_t mA, uint32_t mB, uint32_t mCD) {
+    const bool aA = aL, aB = aT, aC = aT && (mx + 1 < g.mbw || mx > 0);
+    const int ax = aA ? (int)(int8_t)(mA & 255u) : 0, ay = aA ? (int)(int8_t)((mA >> 8) & 255u) : 0;
+    const int bxv = aB ? (int)(int8_t)(mB & 255u) : 0, byv = aB ? (int)(int8_t)((mB >> 8) & 255u) : 0;
+    const int cx = aC ? (int)(int8_t)(mCD & 255u) : 0, cy = aC ? (int)(int8_t)((mCD >> 8) & 255u) : 0;
+    const bool z = !aL || !aT || (ax == 0 && ay == 0) || (bxv == 0 && byv == 0);
+    int pxv, pyv;
+    if (!aB && !aC && aA)
+        pxv = ax, pyv = ay;
+    else if ((int)aA + (int)aB + (int)aC == 1)
+        pxv = aA ? ax : aB ? bxv : cx, pyv = aA ? ay : aB ? byv : cy;
+    else
+        pxv = venc_median3(ax, bxv, cx), pyv = venc_median3(ay, byv, cy);
+    const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
+    return cbp == 0 && (z ? (dx == 0 && dy == 0) : (dx == pxv && dy == pyv));
+}
+
 /* ================================================================== k_entropy_p
  * grid = (segments per slice, slices of the band, (step, item) pairs); block = 256 lanes = the segment's macroblocks.
  *
@@ -79,6 +98,29 @@ DEVFN uint32_t nc_bytes4(uint32_t A, uint32_t Bv, uint32_t mA, uint32_t mB) {
 #endif
 /* (a block of this kernel holds the place of a motion-search block on its CU -- the search takes a CU's whole LDS -- so its LDS is
  * sized for ordinary pictures, 20 KB, not for the worst case, 40 KB; what does not fit goes through memory: same results) */
+/* Diagnostic build only (-DVENC_ENT_STAMPS, tools/ent_stamps.py): the first wave of a block keeps the 100 MHz clock at eight points in registers
+ * and leaves them as ONE record of eight words (ring of VENC_STAMP_PAIRS / 4 records behind B.stamps' eight sums; one atomic per block) */
+#ifdef VENC_ENT_STAMPS
+#define ENT_STAMP(i) do { t_st_[i] = wall_clock64(); } while (0)
+#define ENT_STAMP_INIT unsigned long long t_st_[8]; const unsigned long long t_start_ = wall_clock64()
+#define ENT_STAMP_END                                                                                                         \
+    do {                                                                                                                      \
+        if (threadIdx.x == 0) {                                                                                               \
+            const unsigned long long n_ = atomicAdd(&B.stamps[0], 1ull);                                                      \
+            if (n_ < VENC_STAMP_PAIRS / 4) {                                                                                  \
+                unsigned long long *r_ = B.stamps + 8 + 8 * n_;                                                               \
+                r_[0] = t_start_;                                                                                             \
+                r_[1] = (t_st_[0] - t_start_) | ((unsigned long long)count << 40);                                            \
+                for (int i_ = 1; i_ < 7; i_++) r_[1 + i_] = t_st_[i_] - t_st_[i_ - 1];                                        \
+                r_[7] += t_st_[7] - t_st_[6]; /* (B and its barrier in one word: r_[7] holds 6 -> 7 on top of 5 -> 6) */      \
+            }                                                                                                                 \
+        }                                                                                                                     \
+    } while (0)
+#else
+#define ENT_STAMP_END do { } while (0)
+#define ENT_STAMP(i) do { } while (0)
+#define ENT_STAMP_INIT do { } while (0)
+#endif
 #define ENT_LEN_PUT(rank, val)                                   \
     do {                                                         \
         if ((rank) < ENT_LEN_LDS) s_len[rank] = (uint16_t)(val); \
@@ -90,10 +132,12 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     __shared__ uint32_t s_wa[ENT_THREADS / 64], s_wr[ENT_THREADS / 64], s_wtot[2][ENT_THREADS / 64];
     __shared__ unsigned long long s_mask[ENT_SEG_MBS / 64];
     __shared__ uint32_t s_prev_run;
+    __shared__ uint8_t s_cbp[48]; /* coded_block_pattern -> codeNum (table 9-4, Inter column): from memory it was a dependent round trip in the middle of phase A */
     const int v = blockIdx.z, s = S.slice0 + blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int srow = B.slice_first_row[s];
     const int first = srow * g.mbw, last = B.slice_first_row[s + 1] * g.mbw;
     if (j * ENT_SEG_MBS >= last - first) return;
+    ENT_STAMP_INIT;
     lds_u32 *strip = (lds_u32 *)(s_dyn + tid * 9); /* (written as dwords, read by the coder as int16: may_alias, see venc_kernels.hip) */
     uint16_t *s_len = (uint16_t *)(s_dyn + ENT_THREADS * 9);
     uint32_t *s_cls = s_dyn + ENT_THREADS * 9 + ENT_LEN_LDS / 2, *s_cls2 = s_cls + ENT_CLS_LDS; /* (s_cls2: the empty blocks behind a listed block) */
@@ -110,6 +154,18 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
     const uint4 *ip = (const uint4 *)(infos + mbc), *lp = (const uint4 *)(infos + (aL ? mbc - 1 : mbc)), *tp = (const uint4 *)(infos + (aT ? mbc - g.mbw : mbc));
     const uint4 o0 = ip[0], o1 = ip[1], l0 = lp[0], l1 = lp[1], t0 = tp[0], t1 = tp[1];
     const uint32_t me = mvs[mbc];
+    uint32_t lb_rec = 0, lb_me = 0, lb_a = 0, lb_b = 0, lb_c = 0; /* the look-back's first step (first wave; see below) */
+    if (tid < 64 && j > 0) {
+        const int idx = mb_seg - 1 - lane, ic = idx >= first ? idx : first;
+        int ix, iy;
+        mb_xy(g, ic, ix, iy);
+        const bool lL = ix > 0, lT = iy > srow;
+        lb_rec = ((const uint32_t *)(infos + ic))[6];
+        lb_me = mvs[ic];
+        lb_a = mvs[lL ? ic - 1 : ic];
+        lb_b = mvs[lT ? ic - g.mbw : ic];
+        lb_c = mvs[lT && ix + 1 < g.mbw ? ic - g.mbw + 1 : lT && lL ? ic - g.mbw - 1 : ic];
+    }
     int pxv, pyv;
     bool zero_inferred;
     mv_predict(g, mvs, mbc, mx, aL, aT, pxv, pyv, zero_inferred);
@@ -120,12 +176,14 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                  : i < VENC_TAB_RUN        ? venc_vlc_total_zeros_cdc[i - VENC_TAB_TZ_CDC]
                                            : venc_vlc_run_before[i - VENC_TAB_RUN];
     }
+    if (tid >= 64 && tid < 64 + 48) s_cbp[tid - 64] = venc_cbp_inter_code[tid - 64];
     const int dx = (int)(int8_t)(me & 255u), dy = (int)(int8_t)((me >> 8) & 255u);
     const int cbpl = (int)(o1.z & 15u), cbpc = (int)((o1.z >> 16) & 3u), cbp = cbpl | (cbpc << 4);
     const bool skip = in && cbp == 0 && (zero_inferred ? (dx == 0 && dy == 0) : (dx == pxv && dy == pyv));
     const unsigned long long coded = __ballot(in && !skip);
     if (lane == 0) s_mask[tid >> 6] = coded;
-    uint32_t em = 0, nm = 0; /* bit = slot: entries; those that are blocks with a level (the chroma DC blocks count as such: their record has no count) */
+    uint32_t em = 0, nm = 0, sm = 0; /* bit = slot: entries; those that are blocks with a level (the chroma DC blocks count as such: their record has no
+                                      * count); those of them that hold exactly ONE level (three of four on ordinary content: phase B codes them apart) */
     if (in) {
         if (skip)
             em = (mb == last - 1 || mb == first) ? 1u : 0u; /* the slice's last mb_skip_run / its header */
@@ -141,27 +199,43 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             nm |= 3u << 18;
             nm |= (nonzero_bytes4(o1.x) | (nonzero_bytes4(o1.y) << 4)) << 20;
             nm &= em;
+            const uint32_t k1 = 0x01010101u;
+            const uint32_t oner = (nonzero_bytes4(o0.x ^ k1) | (nonzero_bytes4(o0.y ^ k1) << 4) | (nonzero_bytes4(o0.z ^ k1) << 8) | (nonzero_bytes4(o0.w ^ k1) << 12)) ^ 0xffffu; /* TotalCoeff == 1, raster order */
+#pragma unroll
+            for (int bk = 0; bk < 16; bk++) sm |= ((oner >> (blk_y(bk) * 4 + blk_x(bk))) & 1u) << (2 + bk);
+            sm |= ((nonzero_bytes4(o1.x ^ k1) | (nonzero_bytes4(o1.y ^ k1) << 4)) ^ 0xffu) << 20;
+            sm &= nm & ~(3u << 18);
         }
     }
     /* ranks (bitstream order) and the places in phase B's list: one block scan of three counts */
     /* entries: R, H and the blocks with levels; the coeff_tokens of the blocks WITHOUT a level ride at the end of the entry before
      * them (at most three behind an H, seven behind a block: a coded 8x8 block or a coded chroma AC plane holds a block with levels) */
-    const uint32_t n_all = (uint32_t)__popc(em & (3u | nm)), n_n = (uint32_t)__popc(nm), n_r = em & 1u;
+    const uint32_t n_all = (uint32_t)__popc(em & (3u | nm)), n_n = (uint32_t)__popc(nm), n_r = (em & 1u) | ((uint32_t)__popc(sm) << 16); /* (n_r: R | blocks with one level << 16) */
     const uint32_t ia = wave_scan_incl(n_all | (n_n << 16)), ir = wave_scan_incl(n_r);
     if (lane == 63) s_wa[tid >> 6] = ia, s_wr[tid >> 6] = ir;
-    /* the first wave: P_Skip macroblocks directly before the segment (the run a mb_skip_run of this segment may continue) */
+    /* the first wave: P_Skip macroblocks directly before the segment (the run a mb_skip_run of this segment may continue).  The loads of its
+     * first step -- nearly always the only one -- were issued with the records' above (lb_*): one memory round trip, where the
+     * record -> coded_block_pattern -> neighbours' vectors chain behind the records' made the other three waves wait at the barrier
+     * for a fifth of their lifetime (tools/ent_stamps.py) */
     if (tid < 64) {
         uint32_t prev = 0;
         if (j > 0) {
             int base = mb_seg;
+            bool preloaded = true;
             for (;;) {
                 const int idx = base - 1 - lane;
                 const bool valid = idx >= first;
                 const int ic = valid ? idx : first;
                 int ix, iy;
                 mb_xy(g, ic, ix, iy);
-                const uint32_t rec = ((const uint32_t *)(infos + ic))[6];
-                const bool sk = mb_is_p_skip(g, mvs, ic, ix, ix > 0, iy > srow, (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4));
+                bool sk;
+                if (preloaded)
+                    sk = p_skip_vals(g, ix, ix > 0, iy > srow, (int)(lb_rec & 15u) | (int)(((lb_rec >> 16) & 3u) << 4), lb_me, lb_a, lb_b, lb_c);
+                else {
+                    const uint32_t rec = ((const uint32_t *)(infos + ic))[6];
+                    sk = mb_is_p_skip(g, mvs, ic, ix, ix > 0, iy > srow, (int)(rec & 15u) | (int)(((rec >> 16) & 3u) << 4));
+                }
+                preloaded = false;
                 const unsigned long long cb = __ballot(valid && !sk), vb = __ballot(valid);
                 if (cb) {
                     prev += (uint32_t)__builtin_ctzll(cb);
@@ -174,7 +248,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         }
         if (lane == 0) s_prev_run = prev;
     }
+    ENT_STAMP(0);
     __syncthreads();
+    ENT_STAMP(1);
     uint32_t xa = ia - (n_all | (n_n << 16)), xr = ir - n_r, ta = 0, tr = 0;
 #pragma unroll
     for (int k = 0; k < ENT_THREADS / 64; k++) {
@@ -185,14 +261,16 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         tr += r;
     }
     const size_t seg = ent_seg(g, B, v, s, j);
-    const uint32_t count = ta & 0xffffu, n_r_all = tr, n_rn = tr + (ta >> 16);
+    /* phase B's list: the R entries, the blocks with ONE level, the other blocks with levels (a wave lasts as long as its longest block: apart,
+     * the three blocks of four that hold one level -- noise just above the dead zone -- no longer wait for the fourth) */
+    const uint32_t count = ta & 0xffffu, n_r_all = tr & 0xffffu, n_one = n_r_all + (tr >> 16), n_rn = n_r_all + (ta >> 16);
     uint4 *head = B.ent_head + seg * B.ent_cap;
     uint32_t *cls_mem = B.ent_cls + seg * B.ent_cap, *cls2_mem = B.ent_cls2 + seg * B.ent_cap, *list = B.ent_list + seg * B.ent_cap;
     uint16_t *len_mem = (uint16_t *)(B.ent_off + seg * (B.ent_cap + 4)) + 2 * (B.ent_cap + 4) - B.ent_cap - 8; /* (lengths beyond the LDS part park in the upper half of the segment's
                                                                                                                   offsets, which phase C fills from below: rank k's offset is written after every length <= k was read) */
     if (in) B.ent_mb0[(size_t)v * g.nmb + mb] = (xa & 0xffffu) | (n_all << 16); /* (debug / tests: the macroblock's entries are ranks [lo, lo + hi)) */
     if (em) {
-        uint32_t rank = xa & 0xffffu, pos_r = xr, pos_n = tr + (xa >> 16);
+        uint32_t rank = xa & 0xffffu, pos_r = xr & 0xffffu, pos_s = n_r_all + (xr >> 16), pos_m = n_one + (xa >> 16) - (xr >> 16);
         /* nC of the macroblock's 24 blocks: luma rows ncl[y] (byte = x), chroma planes ncc[plane] (byte = 2 y + x) */
         uint32_t ncl[4], ncc[2];
         {
@@ -240,7 +318,7 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             venc_bs_ue(&hbs, 0u);
             venc_bs_se(&hbs, (dx - pxv) << (g.subpel ? 0 : 2));
             venc_bs_se(&hbs, (dy - pyv) << (g.subpel ? 0 : 2));
-            venc_bs_ue(&hbs, venc_cbp_inter_code[cbp]);
+            venc_bs_ue(&hbs, s_cbp[cbp]);
             if (cbp) venc_bs_se(&hbs, 0);
             uint32_t lead = lev ? blocks & ((1u << __builtin_ctz(lev)) - 1u) : blocks;
             blocks &= ~lead;
@@ -266,8 +344,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
                 }
                 tail = 0;
                 const uint32_t rec = (rank << 18) | ((bq == 16 || bq == 17 ? 0u : 1u + (c == 0u ? 0u : c == 1u ? 2u : c == 2u ? 4u : 8u)) << 13) | ((uint32_t)tid << 5) | (uint32_t)(bq + 2);
+                const uint32_t pos_n = (sm >> (bq + 2)) & 1u ? pos_s++ : pos_m++;
                 if (pos_n < ENT_CLS_LDS) s_cls[pos_n] = rec; else cls_mem[pos_n] = rec;
-                prev_pos = pos_n++;
+                prev_pos = pos_n;
                 rank++;
             } else {
                 const uint32_t n = tail >> 16;
@@ -278,7 +357,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;
         }
     }
+    ENT_STAMP(2);
     __syncthreads();
+    ENT_STAMP(3);
     /* ---------------------------------------------------------------- phase B */
     /* R: slice header, mb_skip_run */
     for (uint32_t k = tid; k < n_r_all; k += ENT_THREADS) {
@@ -311,8 +392,48 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
         if (bits > 128) list[rank] = (uint32_t)mbk << 5;
     }
+    ENT_STAMP(4);
     /* blocks that hold a level (and the chroma DC blocks) */
-    for (uint32_t k = n_r_all + tid; k < n_rn; k += ENT_THREADS) {
+    /* ... exactly ONE level (luma / chroma AC): no level strip in LDS, no loop -- the level's scan position from ORs of the record's eight
+     * dwords, coeff_token (TotalCoeff 1, TrailingOnes 0 / 1), sign or level_prefix / suffix at suffixLength 0, total_zeros = the
+     * position; no run_before.  At most 53 bits + 42 of the empty blocks behind it: assembled in two 64-bit words */
+    for (uint32_t k = n_r_all + tid; k < n_one; k += ENT_THREADS) {
+        const uint32_t e = k < ENT_CLS_LDS ? s_cls[k] : cls_mem[k], rank = e >> 18;
+        const int slot = (int)(e & 31u), mbk = mb_seg + (int)((e >> 5) & 255u), nC = (int)((e >> 13) & 31u) - 1;
+        const bool ac = slot >= 20;
+        const int16_t *lv = B.levels + ((size_t)v * g.nmb + mbk) * VENC_MB_COEFS + ent_level_slot(slot) * 16;
+        const uint4 a = ((const uint4 *)lv)[0], bq = ((const uint4 *)lv)[1];
+        uint32_t tl = k < ENT_CLS_LDS ? s_cls2[k] : cls2_mem[k];
+        const uint32_t d0 = ac ? a.x & 0xffff0000u : a.x;
+        const uint32_t o01 = d0 | a.y, o23 = a.z | a.w, o45 = bq.x | bq.y, o67 = bq.z | bq.w;
+        const uint32_t x = o01 | o23 | o45 | o67;
+        const uint32_t kd = (uint32_t)((a.y | a.w | bq.y | bq.w) != 0u) | ((uint32_t)((o23 | o67) != 0u) << 1) | ((uint32_t)((o45 | o67) != 0u) << 2);
+        const bool hi = (x >> 16) != 0u;
+        const int val = hi ? (int)x >> 16 : (int)(int16_t)(x & 0xffffu);
+        const uint32_t ci = 2u * kd + (hi ? 1u : 0u) - (ac ? 1u : 0u);
+        const uint32_t alv = (uint32_t)(val < 0 ? -val : val), neg = val < 0 ? 1u : 0u;
+        const bool t1 = alv == 1u;
+        const uint32_t tok = s_tab[VENC_TAB_TOKEN + (nC < 2 ? 0 : nC < 4 ? 68 : nC < 8 ? 136 : 204) + 4 + (t1 ? 1 : 0)];
+        const uint32_t code = 2u * alv - 4u + neg; /* levelCode - 2: the first level behind fewer than three trailing ones */
+        const uint32_t lcode = t1 ? neg : code < 14u ? 1u : code < 30u ? 16u | (code - 14u) : 4096u | (code - 30u);
+        const uint32_t llen = t1 ? 1u : code < 14u ? code + 1u : code < 30u ? 19u : 28u;
+        const uint32_t tz = s_tab[VENC_TAB_TZ + ci];
+        unsigned long long acc = (((unsigned long long)(tok & 0xffu) << llen) | lcode) << (tz >> 8) | (tz & 0xffu);
+        const uint32_t n1 = (tok >> 8) + llen + (tz >> 8);
+        unsigned long long tacc = 0;
+        uint32_t n2 = 0;
+        for (uint32_t n = tl >> 16; n; n--, tl >>= 2) { /* the empty blocks behind it: coeff_token of TotalCoeff 0 (1, 11, 1111, 0000 11) */
+            const uint32_t c4 = 4u * (tl & 3u), len = (0x6421u >> c4) & 15u;
+            tacc = (tacc << len) | ((0x3f31u >> c4) & 15u);
+            n2 += len;
+        }
+        const unsigned long long tleft = n2 ? tacc << (64u - n2) : 0ull;
+        const unsigned long long top = (acc << (64u - n1)) | (tleft >> n1), bot = tleft << (64u - n1);
+        ENT_LEN_PUT(rank, n1 + n2);
+        head[rank] = make_uint4((uint32_t)(top >> 32), (uint32_t)top, (uint32_t)(bot >> 32), (uint32_t)bot);
+    }
+    /* ... more (and the chroma DC blocks): the general coder */
+    for (uint32_t k = n_one + tid; k < n_rn; k += ENT_THREADS) {
         const uint32_t e = k < ENT_CLS_LDS ? s_cls[k] : cls_mem[k], rank = e >> 18;
         const int slot = (int)(e & 31u), mbk = mb_seg + (int)((e >> 5) & 255u), nC = (int)((e >> 13) & 31u) - 1;
         const int firstc = slot >= 20 ? 1 : 0, maxc = slot >= 20 ? 15 : slot >= 18 ? 4 : 16;
@@ -341,7 +462,9 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         head[rank] = make_uint4(bs.h0, bs.h1, bs.h2, bs.h3);
         if (bits > 128) list[rank] = ((uint32_t)mbk << 5) | (uint32_t)slot;
     }
+    ENT_STAMP(5);
     __syncthreads();
+    ENT_STAMP(6);
     /* ---------------------------------------------------------------- phase C: bit offsets = exclusive scan of the lengths in rank order */
     uint32_t *off = B.ent_off + seg * (B.ent_cap + 4);
     uint32_t base_bits = 0;
@@ -367,6 +490,8 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
         B.seg_bits[seg] = base_bits;
         B.ent_count[seg] = count;
     }
+    ENT_STAMP(7);
+    ENT_STAMP_END;
 }
 
 /* ================================================================== k_pack_p

@@ -737,8 +737,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipMalloc(&b.nz_rows, (size_t)G * b.nz_item_regions * 64 * 32));
     OPEN_OK(hipMalloc(&b.nz_cnt, (size_t)G * b.nz_item_regions * 4));
     OPEN_OK(hipMemset(b.nz_cnt, 0, (size_t)G * b.nz_item_regions * 4));
-    OPEN_OK(hipMalloc(&b.stamps, 8 * sizeof(unsigned long long)));
-    OPEN_OK(hipMemset(b.stamps, 0, 8 * sizeof(unsigned long long)));
+    OPEN_OK(hipMalloc(&b.stamps, VENC_STAMP_WORDS * sizeof(unsigned long long)));
+    OPEN_OK(hipMemset(b.stamps, 0, VENC_STAMP_WORDS * sizeof(unsigned long long)));
     if (g.subpel) {
         OPEN_OK(hipMalloc(&b.hpel, G * 3 * (size_t)g.cw * g.ch + 64)); /* (+64: k_subpel's aligned row pieces end up to 6 bytes past a row) */
         OPEN_OK(hipMalloc(&b.mvq, (size_t)VENC_RING * G * nmb * 4));
@@ -1655,7 +1655,7 @@ extern "C" int venc_debug_read(venc_ctx *c, int what, int item, void *dst, size_
         case 6: src = rec + (size_t)g.cw * g.ch * 5 / 4, n = (size_t)g.cw * g.ch / 4; break;
         case 7: src = c->b.mboff + item * nmb, n = nmb * 4; break;
         case 9: src = c->b.me_cnt + item * nmb, n = nmb; break;
-        case 11: src = c->b.stamps, n = 8 * sizeof(unsigned long long); break;
+        case 11: src = c->b.stamps, n = VENC_STAMP_WORDS * sizeof(unsigned long long); break;
         case 10: src = c->b.me_flag + item * nmb, n = nmb; break;
         case 12: src = c->b.intra_d0 + item * nmb * 32, n = nmb * 32 * 4; break;
         case 13: src = c->b.intra_rec + item * nmb * INTRA_REC_DWORDS, n = nmb * INTRA_REC_DWORDS * 4; break;

@@ -55,6 +55,8 @@ typedef struct {
     uint32_t pad;
 } venc_out_header;
 
+#define VENC_STAMP_PAIRS 16384
+#define VENC_STAMP_WORDS (8 + 2 * VENC_STAMP_PAIRS)
 typedef struct {
     int w, h;        /* display */
     int cw, ch;      /* coded */
@@ -143,7 +145,7 @@ typedef struct {
                                    pointers): the search of a step zeroes the other set, which the next step's search fills */
     uint32_t *fix_count_next;
     uint32_t *fix_list;         /* [G][nmb] their indices */
-    unsigned long long *stamps; /* [8] diagnostic cycle sums (VENC_ME_STAMPS builds) */
+    unsigned long long *stamps; /* [VENC_STAMP_WORDS] diagnostic builds (VENC_ME_STAMPS, VENC_ENT_STAMPS): 8 sums, then (start, end) clock pairs of blocks */
     uint8_t *me_cnt;            /* [G][nmb] candidates that passed the lower-bound test (saturating) */
     /* 4x4 luma blocks with a level, listed by the search's P5 for the extra blocks of the k_me_fix launch (venc_inter2.hip
      * luma_block_defer): one 64-entry segment per (tile, transforming wave), entry = lane | cx << 6 | cy << 12 */
