@@ -580,6 +580,8 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             res["config"]["exchanges_per_picture"] = round(res["config"]["exchanges_per_step"] * min(gop_batch, n_gops) / float(frames), 4)
             if c_exchange:
                 res["config"]["rccl_ranks"] = int(venc.hip_lib().venc_rccl_comm_count(eng))  # ncclCommCount of the engine's communicator
+                # P steps whose search ran as interior tile rows (beside the exchange, on its own stream) + edge tile rows (behind it)
+                res["config"]["search_split_steps_per_step"] = int(venc.hip_lib().venc_band_split_steps(eng)) // max(1, steps + warmup)
             if world > 1:
                 whole = stream_info.get("frames", [])
                 res["config"]["bytes_per_step"] = sum(len(f) for f in whole)
@@ -801,7 +803,7 @@ def main():
                 out["slices_2160p"] = {"value": slices.get("value"), "unit": "Mpixels/s", "ms_per_step": slices.get("ms_per_step"), "steps": slices.get("steps"),
                                        "n_gpus": slices.get("n_gpus"), "scaling": "strong", "parallelism": c5.get("parallelism"), "exchange": c5.get("exchange"),
                                        "exchanges_per_step": c5.get("exchanges_per_step"), "exchanges_per_picture": c5.get("exchanges_per_picture"),
-                                       "rccl_ranks": c5.get("rccl_ranks"), "bitstream_sha256": c5.get("bitstream_sha256"),
+                                       "rccl_ranks": c5.get("rccl_ranks"), "search_split_steps_per_step": c5.get("search_split_steps_per_step"), "bitstream_sha256": c5.get("bitstream_sha256"),
                                        "one_rank_sha256": c5.get("one_rank_sha256"), "equals_one_rank_bitstream": c5.get("equals_one_rank_bitstream"),
                                        "leg_wall_s": slices.get("leg_wall_s"), "roofline": slices.get("roofline"),
                                        "note": "measured by a second set of rank processes before the streams run (bench.py slices_leg); control plane gloo, data path RCCL inside the engine"}

@@ -141,6 +141,17 @@ int venc_band_export(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride
 int venc_band_import(venc_ctx *c, int n_items, const void *d_chunk, size_t item_stride, int slice_first, int slice_count,
                      int halo_rows);
 void *venc_stream_handle(venc_ctx *c); /* hipStream_t of the main kernel chain */
+/* The exchange off the main chain.  Between venc_band_xbegin() and venc_band_xend() the export, the transfer (on venc_band_stream())
+ * and the imports are enqueued on the context's EXCHANGE stream, behind everything the main stream has been given so far.  The next P
+ * step then launches its motion search twice: the tile rows whose search windows stay inside the own band at once -- beside the
+ * exchange --, the band's first / last tile row (the only ones that read a neighbour's rows) once the exchange has finished;
+ * whatever else reads the reconstruction follows those on the main stream.  Without the pair (or with VENC_XOVERLAP=0) everything
+ * stays on the main stream as before.  venc_band_exchange_rccl() uses the pair itself.  venc_band_split_steps(): P steps whose
+ * search ran as two launches (tests, benchmarks).  Unmeasured on hardware with more than one GPU. */
+int venc_band_xbegin(venc_ctx *c);
+int venc_band_xend(venc_ctx *c);
+void *venc_band_stream(venc_ctx *c); /* hipStream_t band copies and the transfer belong on right now */
+long long venc_band_split_steps(const venc_ctx *c);
 
 /* ---- RCCL exchange: the three steps above as ONE call, in C, on RCCL over xGMI (csrc/venc_rccl.hip) ----
  * One communicator per context.  One process per GPU: rank 0 calls venc_rccl_unique_id, any out-of-band channel carries

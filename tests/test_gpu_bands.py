@@ -18,16 +18,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("w,h,n_slices,cuts,halo_rows,items,deblock", [
-    (352, 288, 6, (0, 2, 6), 0, 1, False),        # two bands, whole-band exchange
-    (352, 288, 6, (0, 1, 3, 6), 16, 1, False),    # three bands (one of a single slice), halo exchange
-    (1920, 1088, 8, (0, 3, 8), 16, 2, False),     # full-HD geometry, odd first band row count, two items in lock-step
-    (352, 288, 6, (0, 1, 3, 6), 16, 1, True),     # in-loop filter inside slices (idc 2): bands stay independent, halos carry filtered rows
+@pytest.mark.parametrize("w,h,n_slices,cuts,halo_rows,items,deblock,xstream", [
+    (352, 288, 6, (0, 2, 6), 0, 1, False, False),        # two bands, whole-band exchange
+    (352, 288, 6, (0, 1, 3, 6), 16, 1, False, False),    # three bands (one of a single slice), halo exchange
+    (1920, 1088, 8, (0, 3, 8), 16, 2, False, False),     # full-HD geometry, odd first band row count, two items in lock-step
+    (352, 288, 6, (0, 1, 3, 6), 16, 1, True, False),     # in-loop filter inside slices (idc 2): bands stay independent, halos carry filtered rows
+    (1920, 1088, 8, (0, 3, 5, 8), 16, 2, False, True),   # the exchange on the exchange stream: the next search as interior + edge launches
+    (1920, 1088, 8, (0, 3, 8), 0, 1, False, True),       # ... whole-band exchange
+    (352, 288, 6, (0, 1, 3, 6), 16, 1, True, True),      # ... bands too short to split (one or two tile rows): the step waits instead
 ])
-def test_band_engines_reproduce_the_whole_picture_engine(venc, orc, w, h, n_slices, cuts, halo_rows, items, deblock):
+def test_band_engines_reproduce_the_whole_picture_engine(venc, orc, w, h, n_slices, cuts, halo_rows, items, deblock, xstream):
     """One engine per band on the same GPU, rows swapped with venc_band_export / venc_band_import through a
     device chunk: slices, motion vectors and (whole-band mode) every rank's full reconstruction equal the
-    whole-picture engine's, which equals the oracle's."""
+    whole-picture engine's, which equals the oracle's.  xstream: export and imports between venc_band_xbegin / venc_band_xend
+    (the exchange stream); the engines are NOT synchronised between the imports and the next step, which must then launch the
+    tile rows that read no neighbour's row beside the imports and the edge rows behind them."""
     import torch
     n, keyint, qp = 5, 4, 27
     clips = [[venc.synth_frame(w, h, t, 0x1234ABCD + 17 * i) for t in range(n)] for i in range(items)]
@@ -63,20 +68,34 @@ def test_band_engines_reproduce_the_whole_picture_engine(venc, orc, w, h, n_slic
             assert want == [unescape(b) for (ty, _, b) in split_nals(ref.data) if ty in (1, 5)], "oracle, frame %d" % t
         # exchange (the next picture may be P)
         for k, (e, a, c) in enumerate(bands):
+            if xstream:
+                e.band_xbegin()
             assert e.band_export(items, chunks[k].data_ptr(), stride, halo_rows) > 0
-            e.sync()
+            if not xstream:
+                e.sync()
+        if xstream:
+            torch.cuda.synchronize()  # (every band's chunk is packed before a peer unpacks it: what the transfer's own ordering does between GPUs)
         for k, (e, a, c) in enumerate(bands):
             peers = [j for j in (k - 1, k + 1) if 0 <= j < len(bands)] if halo_rows else \
                     [j for j in range(len(bands)) if j != k]
             for j in peers:
                 e.band_import(items, chunks[j].data_ptr(), stride, bands[j][1], bands[j][2], halo_rows)
-            e.sync()
+            if xstream:
+                e.band_xend()   # no synchronisation: the next step's search overlaps the imports
+            else:
+                e.sync()
         if halo_rows == 0:
             for i in range(items):
                 for p in range(3):
                     full = whole.debug(4 + p, i)
                     for e, _, _ in bands:
                         assert np.array_equal(e.debug(4 + p, i), full), "frame %d item %d plane %d" % (t, i, p)
+    if xstream:
+        # P steps behind an exchange: frames 1 .. n - 1 except the IDRs; bands of three or more tile rows split their search
+        n_p = sum(1 for t in range(1, n) if t % keyint != 0)
+        for (e, a, c), (r0, r1) in zip(bands, rows):
+            splits = e.band_split_steps()
+            assert splits == (n_p if (r1 - r0 + 1) // 2 >= 3 else 0), "band %d..%d: %d split steps" % (a, a + c, splits)
     for e in [whole] + [b[0] for b in bands]:
         e.close()
 

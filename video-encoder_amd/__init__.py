@@ -166,6 +166,12 @@ def bind_hip(L):
         L.venc_search_split.argtypes = [C.c_void_p]
         L.venc_stream_handle.restype = C.c_void_p
         L.venc_stream_handle.argtypes = [C.c_void_p]
+        L.venc_band_xbegin.argtypes = [C.c_void_p]
+        L.venc_band_xend.argtypes = [C.c_void_p]
+        L.venc_band_stream.restype = C.c_void_p
+        L.venc_band_stream.argtypes = [C.c_void_p]
+        L.venc_band_split_steps.restype = C.c_longlong
+        L.venc_band_split_steps.argtypes = [C.c_void_p]
         L.venc_rccl_unique_id.argtypes = [C.c_void_p]
         L.venc_rccl_init_rank.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.venc_rccl_init_all.argtypes = [C.POINTER(C.c_void_p), C.c_int]
@@ -454,6 +460,19 @@ class Engine:
     def band_import(self, n_items, dev_ptr, item_stride, slice_first, slice_count, halo_rows=0):
         return self._ok(self.L.venc_band_import(self.h, n_items, C.c_void_p(dev_ptr), item_stride, slice_first,
                                                 slice_count, halo_rows), "venc_band_import")
+
+    def band_xbegin(self):
+        """export / import until band_xend() go to the exchange stream; the next P step splits its search around them"""
+        return self._ok(self.L.venc_band_xbegin(self.h), "venc_band_xbegin")
+
+    def band_xend(self):
+        return self._ok(self.L.venc_band_xend(self.h), "venc_band_xend")
+
+    def band_stream(self):
+        return self.L.venc_band_stream(self.h)
+
+    def band_split_steps(self):
+        return int(self.L.venc_band_split_steps(self.h))
 
     def stream_handle(self):
         return self.L.venc_stream_handle(self.h)

@@ -141,6 +141,17 @@ struct venc_ctx {
     int parity;           /* reconstruction buffer the next step writes; rec_last: the one the last step wrote (the next reference) */
     int rec_last;
     hipStream_t stream3;  /* intra steps running ahead */
+    /* EXCHANGE STREAM (slice bands): between venc_band_xbegin and venc_band_xend the band's export, the
+     * collective and the import of the peers' rows run on stream_x, behind everything the main stream has done so far.  The next P step's search
+     * then goes as TWO launches: the tile rows whose 64-row windows stay inside the own band at once, beside the exchange; the first /
+     * last tile row of a band that has a neighbour above / below after ev_x_done.  Everything else that reads the reconstruction
+     * follows those on the main stream.  (VENC_XOVERLAP=0: the exchange stays on the main stream, as until round 3.) */
+    hipStream_t stream_x;
+    hipEvent_t ev_x_main, ev_x_done;
+    int x_overlap;          /* VENC_XOVERLAP (default 1) */
+    int x_active;           /* between xbegin and xend: band copies go to stream_x */
+    int x_pending;          /* ev_x_done recorded and not yet waited for by the main stream */
+    long long x_split_steps; /* P steps whose search ran as interior + edge launches */
     hipEvent_t ev_intra;  /* the last intra step on stream3 done */
     int intra_pending;    /* ev_intra recorded and not yet waited for by the main stream */
     int intra_async_last; /* the open entropy batch holds an intra step that ran on stream3 */
@@ -313,6 +324,7 @@ extern "C" void venc_close(venc_ctx *c) {
     (void)hipSetDevice(c->cfg.device);
     if (c->stream && c->stream2 && c->b.mbbits) (void)entropy_flush(c);
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
+    if (c->stream_x) (void)hipStreamSynchronize(c->stream_x);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     rccl_release(c);
     if (c->stream2) (void)hipStreamSynchronize(c->stream2);
@@ -336,6 +348,9 @@ extern "C" void venc_close(venc_ctx *c) {
     if (c->ev_chroma) (void)hipEventDestroy(c->ev_chroma);
     if (c->stream3) (void)hipStreamSynchronize(c->stream3);
     if (c->ev_intra) (void)hipEventDestroy(c->ev_intra);
+    if (c->ev_x_main) (void)hipEventDestroy(c->ev_x_main);
+    if (c->ev_x_done) (void)hipEventDestroy(c->ev_x_done);
+    if (c->stream_x) (void)hipStreamDestroy(c->stream_x);
     for (int i = 0; i < VENC_BHIST; i++) {
         if (c->bh[i].ev_main) (void)hipEventDestroy(c->bh[i].ev_main);
         if (c->bh[i].ev_chroma) (void)hipEventDestroy(c->bh[i].ev_chroma);
@@ -524,6 +539,10 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     OPEN_OK(hipEventCreateWithFlags(&c->ev_chroma, hipEventDisableTiming));
     OPEN_OK(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     OPEN_OK(hipEventCreateWithFlags(&c->ev_intra, hipEventDisableTiming));
+    OPEN_OK(hipStreamCreateWithFlags(&c->stream_x, hipStreamNonBlocking));
+    OPEN_OK(hipEventCreateWithFlags(&c->ev_x_main, hipEventDisableTiming));
+    OPEN_OK(hipEventCreateWithFlags(&c->ev_x_done, hipEventDisableTiming));
+    c->x_overlap = getenv("VENC_XOVERLAP") ? atoi(getenv("VENC_XOVERLAP")) != 0 : 1;
     for (int i = 0; i < VENC_BHIST; i++) {
         OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_main, hipEventDisableTiming));
         OPEN_OK(hipEventCreateWithFlags(&c->bh[i].ev_chroma, hipEventDisableTiming));
@@ -962,6 +981,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
     const bool two = c->two_chain && !is_idr && c->overlap && n_items >= 2 && c->me_mode == 0 && !c->inter_legacy && c->fuse_luma == 3 && me_blocks_env != 3 && !c->g.subpel &&
                      !c->cfg.deblock && !c->rc_comm && c->band_s0 == 0 && c->band_s1 == c->g.n_slices && !c->me_xcd;
     const int n_a = two ? (n_items + 1) / 2 : n_items;
+    if (c->x_pending && (is_idr || two)) { /* an exchange in flight on stream_x: a P step takes it in at its search (below), any other step here */
+        HIP_OK(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));
+        c->x_pending = 0;
+    }
     if (!two) {
         HIP_OK(main_joins_b(c));
         c->b_behind = 1;
@@ -1100,6 +1123,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
         int nz_regions = 0, nz_ntx = 1;
         uint32_t nz_magic = 0;
         if (c->me_mode != 0) HIP_OK(hipMemsetAsync(b.fix_count_next, 0, (size_t)c->b.max_items * 4, s1));
+        if (c->x_pending && c->me_mode != 0) { /* (the first-generation searches do not split) */
+            HIP_OK(hipStreamWaitEvent(s1, c->ev_x_done, 0));
+            c->x_pending = 0;
+        }
         prof_begin(c, KID_ME, s1);
 #ifdef VENC_LEGACY_KERNELS
         if (c->me_mode == 2)
@@ -1127,6 +1154,31 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
              * chain waits for whole CUs wherever it may run. */
             static const int me_blocks = getenv("VENC_ME_BLOCKS") ? atoi(getenv("VENC_ME_BLOCKS")) : 4;
             const bool pool4 = me_blocks != 3 && (fuse_arg == 0 || fuse_arg == 3);
+            /* An exchange in flight on stream_x (slice bands): the tile rows whose windows (tile rows +- 16 luma rows) stay inside the own band
+             * go first, beside the exchange; the band's first / last tile row -- where a neighbour's rows are read -- after it.  A launch
+             * takes its tiles from two runs: [tile0, tile0 + tile_split) and [tile1, ...), tile_n in all. */
+            S.tile0 = S.tile1 = 0;
+            S.tile_split = S.tile_n = ntx * nty;
+            const bool has_up = S.row0 > 0, has_dn = S.row1 < g.mbh;
+            const bool x_split = c->x_pending && pool4 && !two && !c->me_xcd && (has_up || has_dn) && nty >= 3;
+            if (c->x_pending && !x_split) {
+                HIP_OK(hipStreamWaitEvent(s1, c->ev_x_done, 0));
+                c->x_pending = 0;
+            }
+            for (int part = 0; part < (x_split ? 2 : 1); part++) {
+                int gxp = gx;
+                if (x_split) {
+                    const int lo = has_up ? 1 : 0, hi = nty - (has_dn ? 1 : 0);
+                    if (part == 0) {
+                        S.tile0 = lo * ntx, S.tile_split = S.tile_n = (hi - lo) * ntx, S.tile1 = 0;
+                    } else {
+                        HIP_OK(hipStreamWaitEvent(s1, c->ev_x_done, 0));
+                        c->x_pending = 0;
+                        c->x_split_steps++;
+                        S.tile0 = 0, S.tile_split = has_up ? ntx : 0, S.tile1 = (nty - 1) * ntx, S.tile_n = ((has_up ? 1 : 0) + (has_dn ? 1 : 0)) * ntx;
+                    }
+                    gxp = S.tile_n;
+                }
             for (int half = 0; half < (two ? 2 : 1); half++) {
                 venc_step Sh = S;
                 Sh.item0 = half ? n_a : 0;
@@ -1134,14 +1186,17 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
                 hipStream_t sh = half ? c->stream_b : s1;
                 if (half) prof_end(c, s1); /* (the timed launches are the main stream's: half the items) */
                 if (pool4 && c->cfg.rc_mode)
-                    hipLaunchKernelGGL(k_me_pool4<true>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                    hipLaunchKernelGGL(k_me_pool4<true>, dim3(gxp, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
                 else if (pool4)
-                    hipLaunchKernelGGL(k_me_pool4<false>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                    hipLaunchKernelGGL(k_me_pool4<false>, dim3(gxp, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
                 else if (c->cfg.rc_mode)
                     hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
                 else
                     hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
             }
+            }
+            S.tile0 = S.tile1 = 0;
+            S.tile_split = S.tile_n = ntx * nty;
             if (fuse_arg == 3) nz_regions = 4 * ntx * nty, nz_ntx = ntx, nz_magic = tx_magic;
         }
         prof_end(c, s1);
@@ -1413,6 +1468,20 @@ extern "C" size_t venc_band_chunk_bytes(const venc_ctx *c, int mb_rows, int halo
     return n < 0 ? 0 : (size_t)n;
 }
 
+/* what a band copy on the main stream (or the start of an exchange on stream_x) follows: the open entropy batch (its chroma transforms are
+ * launched with it), the second chain, the chroma transforms, an intra step that ran ahead */
+static int band_main_ready(venc_ctx *c) {
+    if (entropy_flush(c) != 0) return -1;
+    HIP_OK(main_joins_b(c));
+    c->b_behind = 1;
+    HIP_OK(main_waits_for_chroma(c));
+    if (c->intra_pending) { /* (band engines code their intra steps on the main stream; an engine may change mode) */
+        HIP_OK(hipStreamWaitEvent(c->stream, c->ev_intra, 0));
+        c->intra_pending = 0;
+    }
+    return 0;
+}
+
 static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride, int row0, int row1, int halo_rows, int to_chunk) {
     venc_band_job J;
     const int bytes = band_job(c, row0, row1, halo_rows, &J);
@@ -1423,24 +1492,48 @@ static int band_copy(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride
         return -1;
     }
     HIP_OK(hipSetDevice(c->cfg.device));
-    if (entropy_flush(c) != 0) return -1; /* (the chroma transforms of an open batch are launched with it) */
-    HIP_OK(main_joins_b(c));
-    c->b_behind = 1;
-    HIP_OK(main_waits_for_chroma(c));
+    if (!c->x_active && band_main_ready(c) != 0) return -1;
     J.to_chunk = to_chunk;
     J.item_stride = item_stride;
     uint32_t big = 0;
     for (int i = 0; i < J.n_seg; i++) big = J.seg[i].bytes > big ? J.seg[i].bytes : big;
     int blocks = (int)((big / 16 + 1023) / 1024); /* four trips per lane */
     if (blocks < 1) blocks = 1;
-    if (c->intra_pending) { /* (band engines code their intra steps on the main stream; an engine may change mode) */
-        HIP_OK(hipStreamWaitEvent(c->stream, c->ev_intra, 0));
-        c->intra_pending = 0;
-    }
-    hipLaunchKernelGGL(k_band_copy, dim3(blocks, J.n_seg, n_items), dim3(256), 0, c->stream, c->b, c->rec_last, J, (uint8_t *)d_chunk);
+    hipLaunchKernelGGL(k_band_copy, dim3(blocks, J.n_seg, n_items), dim3(256), 0, c->x_active ? c->stream_x : c->stream, c->b, c->rec_last, J, (uint8_t *)d_chunk);
     HIP_OK(hipGetLastError());
     return bytes;
 }
+
+/* the exchange stream (see venc_ctx): between these two calls venc_band_export / venc_band_import are enqueued on it */
+extern "C" int venc_band_xbegin(venc_ctx *c) {
+    if (!c || c->x_active) {
+        SET_ERR("venc_band_xbegin: %s", c ? "already open" : "no context");
+        return -1;
+    }
+    if (!c->x_overlap) return 0; /* (everything stays on the main stream) */
+    HIP_OK(hipSetDevice(c->cfg.device));
+    if (band_main_ready(c) != 0) return -1;
+    if (c->x_pending) { /* (an exchange nobody consumed: the main stream takes it in before the next one starts) */
+        HIP_OK(hipStreamWaitEvent(c->stream, c->ev_x_done, 0));
+        c->x_pending = 0;
+    }
+    HIP_OK(hipEventRecord(c->ev_x_main, c->stream));
+    HIP_OK(hipStreamWaitEvent(c->stream_x, c->ev_x_main, 0));
+    c->x_active = 1;
+    return 0;
+}
+extern "C" int venc_band_xend(venc_ctx *c) {
+    if (!c) return -1;
+    if (!c->x_active) return 0;
+    HIP_OK(hipSetDevice(c->cfg.device));
+    HIP_OK(hipEventRecord(c->ev_x_done, c->stream_x));
+    c->x_active = 0;
+    c->x_pending = 1;
+    return 0;
+}
+/* the stream band copies and the collective of an open exchange belong on (the main stream without one) */
+extern "C" void *venc_band_stream(venc_ctx *c) { return c ? (void *)(c->x_active ? c->stream_x : c->stream) : NULL; }
+extern "C" long long venc_band_split_steps(const venc_ctx *c) { return c ? c->x_split_steps : 0; }
 
 extern "C" int venc_band_export(venc_ctx *c, int n_items, void *d_chunk, size_t item_stride, int halo_rows) {
     return band_copy(c, n_items, d_chunk, item_stride, c->slice_rows[c->band_s0], c->slice_rows[c->band_s1], halo_rows, 1);
@@ -1503,6 +1596,8 @@ extern "C" int venc_wait_issued(venc_ctx *c, int ticket) {
 }
 extern "C" int venc_sync(venc_ctx *c) {
     if (entropy_flush(c) != 0) return -1;
+    HIP_OK(hipStreamSynchronize(c->stream_x));
+    c->x_pending = 0;
     HIP_OK(hipStreamSynchronize(c->stream_copy));
     HIP_OK(hipStreamSynchronize(c->stream3));
     HIP_OK(hipStreamSynchronize(c->stream_b));

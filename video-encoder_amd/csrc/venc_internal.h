@@ -81,6 +81,7 @@ typedef struct {
     /* band of the picture coded by this context (slice-parallel multi-GPU mode, venc_set_band);
      * the whole picture by default: slices [slice0, slice1) = MB rows [row0, row1) = macroblocks [mb0, mb1) */
     int slice0, slice1, row0, row1, mb0, mb1;
+    int tile0, tile_split, tile1, tile_n; /* k_me_pool4: the launch's blocks 0 .. tile_n - 1 are the tiles [tile0, tile0 + tile_split) and [tile1, ...) (one run by default; two launches while an exchange is in flight) */
     int me_fast; /* k_me_pool: bounds tested as they are computed (VENC_ME_FAST=0: always the kept-bounds pass) */
     int me_stop; /* diagnostic (VENC_ME_STOP=n): k_me_tile returns after phase n; results are then meaningless */
     int in_slot[VENC_MAX_ITEMS];

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint16_t *rank = B.me_rank;
     const int item = (int)blockIdx.z + S.item0;
     const int kx = (int)(blockIdx.x >> 3);
-    const int tile = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
-    if (tile >= tiles_x * tiles_y) return;
+    const int tile_l = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
+    if (tile_l >= S.tile_n) return;
+    const int tile = tile_l < S.tile_split ? tile_l + S.tile0 : tile_l - S.tile_split + S.tile1; /* (one run of tiles, or the two edge rows of a band: venc_hip.hip) */
     if (tile == 0 && threadIdx.x == 0) {
         B.fix_count_next[item] = 0;
         if (RC) {

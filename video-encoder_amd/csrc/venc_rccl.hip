@@ -122,6 +122,7 @@ static int rccl_buffers(venc_ctx *c, int n_items, int halo_rows) {
     }
     if (c->rc_send && chunk == c->rc_item_stride && n_items <= c->rc_items && halo_rows == c->rc_halo) return 0;
     HIP_OK(hipStreamSynchronize(c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream_x));
     (void)hipFree(c->rc_send);
     (void)hipFree(c->rc_recv);
     c->rc_send = c->rc_recv = NULL;
@@ -235,21 +236,28 @@ extern "C" int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows) 
     if (rccl_buffers(c, n_items, halo_rows) != 0) return -1;
     const size_t stride = c->rc_item_stride, rank_bytes = stride * (size_t)c->rc_items;
     uint8_t *send = (uint8_t *)c->rc_send, *recv = (uint8_t *)c->rc_recv;
-    if (venc_band_export(c, n_items, send, stride, halo_rows) < 0) return -1;
+    /* pack, collective and unpack on the exchange stream (venc_hip.hip EXCHANGE STREAM): the next P step's search starts on the main stream
+     * with the tile rows that read no neighbour's row and takes the exchange in before the band's first / last tile row */
+    if (venc_band_xbegin(c) != 0) return -1;
+    const hipStream_t xs = (hipStream_t)venc_band_stream(c);
+    if (venc_band_export(c, n_items, send, stride, halo_rows) < 0) {
+        (void)venc_band_xend(c);
+        return -1;
+    }
     if (c->rc_poison) /* tests: a chunk consumed before its collective has run shows up in the reconstruction */
-        HIP_OK(hipMemsetAsync(recv, 0xA5, rank_bytes * (size_t)c->rc_world, c->stream));
+        HIP_OK(hipMemsetAsync(recv, 0xA5, rank_bytes * (size_t)c->rc_world, xs));
     const int lo = c->rc_rank - 1, hi = c->rc_rank + 1;
     if (halo_rows > 0) {
         NCCL_OK(g_nccl.GroupStart());
         for (int k = 0; k < 2; k++) {
             const int peer = k ? hi : lo;
             if (peer < 0 || peer >= c->rc_world) continue;
-            NCCL_OK(g_nccl.Send(send, stride * (size_t)n_items, ncclUint8, peer, c->rc_comm, c->stream));
-            NCCL_OK(g_nccl.Recv(recv + (size_t)peer * rank_bytes, stride * (size_t)n_items, ncclUint8, peer, c->rc_comm, c->stream));
+            NCCL_OK(g_nccl.Send(send, stride * (size_t)n_items, ncclUint8, peer, c->rc_comm, xs));
+            NCCL_OK(g_nccl.Recv(recv + (size_t)peer * rank_bytes, stride * (size_t)n_items, ncclUint8, peer, c->rc_comm, xs));
         }
         NCCL_OK(g_nccl.GroupEnd());
     } else {
-        NCCL_OK(g_nccl.AllGather(send, recv, rank_bytes, ncclUint8, c->rc_comm, c->stream));
+        NCCL_OK(g_nccl.AllGather(send, recv, rank_bytes, ncclUint8, c->rc_comm, xs));
     }
     c->rc_exchanges++;
     if (g_group_depth > 0) { /* the collective is only recorded so far: unpack at venc_rccl_group_end */
@@ -263,7 +271,8 @@ extern "C" int venc_band_exchange_rccl(venc_ctx *c, int n_items, int halo_rows) 
         g_n_pending++;
         return 0;
     }
-    return rccl_import_peers(c, n_items, halo_rows);
+    if (rccl_import_peers(c, n_items, halo_rows) != 0) return -1;
+    return venc_band_xend(c);
 }
 
 /* single-process multi-GPU hosts bracket the per-context exchange calls of one picture with these; the peers' rows are
@@ -290,7 +299,7 @@ extern "C" int venc_rccl_group_end(void) {
     }
     int rc = 0;
     for (int i = 0; i < n; i++)
-        if (rccl_import_peers(g_pending[i].c, g_pending[i].n_items, g_pending[i].halo_rows) != 0) rc = -1;
+        if (rccl_import_peers(g_pending[i].c, g_pending[i].n_items, g_pending[i].halo_rows) != 0 || venc_band_xend(g_pending[i].c) != 0) rc = -1;
     return rc;
 }
 
