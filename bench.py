@@ -744,6 +744,9 @@ def main():
                 dist.barrier()
 
     venc = importlib.import_module("video-encoder_amd")
+    # one process per GPU, on the CPUs of its card's NUMA node (what numactl does in a launcher; include/venc_hip.h venc_numa_bind):
+    # on a two-socket host an unbound process keeps the socket it happened to start on, and the far one costs ~5 %
+    numa_node = venc.hip_lib().venc_numa_bind(local_rank, 1) if os.environ.get("VENC_NUMA_BIND", "1") != "0" else -1
     ORACLE_OPTS.update(crf=args.crf, intra_modes=args.intra_modes, subpel=args.subpel, deblock=args.deblock)
     slices_mode = args.mode == "slices"
     solo = world == 1 and not slices_mode
@@ -771,6 +774,7 @@ def main():
             "data": "synthetic",
             "config": res["config"],
         }
+        out["config"]["host_numa_node"] = numa_node  # -1: not bound (one node, no sysfs, or VENC_NUMA_BIND=0)
         for k in ("per_pass", "roofline", "roofline_valu", "kernel_ms_per_step", "kernel_ms_per_step_isolated"):
             if res.get(k) is not None:
                 out[k] = res[k]

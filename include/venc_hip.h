@@ -82,6 +82,13 @@ int venc_abi_version(void);
 const char *venc_last_error(void);
 int venc_device_count(void);
 int venc_device_memory(int device, size_t *free_bytes, size_t *total_bytes); /* 0 = ok */
+/* Host threads beside their GPU: restricts the calling thread (scope 0; threads it creates later inherit) or every thread of the
+ * process (scope 1) to the CPUs of the card's NUMA node (sysfs: PCI bus id -> numa_node -> cpulist, intersected with the CPUs the
+ * caller may use).  Returns the node, or -1 when there was nothing to do.  venc_open() calls it with scope 0 for the thread that opens
+ * an engine -- the one that will launch its kernels -- unless VENC_NUMA_BIND=0 (2: scope 1).  On a two-socket host an unbound run
+ * keeps whichever socket it started on: 162 - 173 Gpx/s at 1080p against 177 - 183 bound (NOTEBOOK.md section 10).  A launcher that
+ * starts one process per GPU does the same with numactl / taskset before the process starts. */
+int venc_numa_bind(int device, int scope);
 
 int venc_open(const venc_config *cfg, venc_ctx **out);
 void venc_close(venc_ctx *c);

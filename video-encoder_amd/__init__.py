@@ -166,6 +166,7 @@ def bind_hip(L):
         L.venc_search_split.argtypes = [C.c_void_p]
         L.venc_stream_handle.restype = C.c_void_p
         L.venc_stream_handle.argtypes = [C.c_void_p]
+        L.venc_numa_bind.argtypes = [C.c_int, C.c_int]
         L.venc_band_xbegin.argtypes = [C.c_void_p]
         L.venc_band_xend.argtypes = [C.c_void_p]
         L.venc_band_stream.restype = C.c_void_p

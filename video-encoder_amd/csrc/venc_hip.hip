@@ -17,6 +17,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <dirent.h>
+#include <sched.h>
 
 #include "../../include/venc_hip.h"
 #include "venc_lines.h"
@@ -192,7 +194,7 @@ struct venc_ctx {
     int intra_waves;
     int last_batch_p; /* the last entropy batch coded P pictures (venc_debug_read derives their per-macroblock bits from the entries) */
     venc_step last_batch_S;
-    int me_xcd;       /* VENC_ME_XCD=1: XCD-aware tile order in k_me_pool (less fabric traffic, slightly slower) */
+    int me_xcd;       /* XCD-aware tile order of the search (VENC_ME_XCD; default from 200 000 macroblocks per step, see venc_open) */
     int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
     int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
     int max_slice_mbs;
@@ -315,6 +317,65 @@ extern "C" int venc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+
+/* ---- host threads beside their GPU.  A two-socket host reaches the card through ONE socket; a thread that launches kernels, rings
+ * doorbells and polls pinned memory from the other socket pays the inter-socket hop on every one of those (measured on the round-4
+ * boxes, 2 x EPYC 9575F, same box, medians of four runs: 1080p 171.5 Gpx/s unbound (162 - 173: a run keeps the socket it started
+ * on), 179.2 bound to the card's node, 173.0 bound to the other one).  venc_numa_bind(device, scope): the card's NUMA node from
+ * sysfs (PCI bus id -> numa_node -> cpulist), intersected with the CPUs the caller may use; scope 0 = the calling thread (threads it
+ * creates later inherit), 1 = every thread of the process (the HIP runtime's included).  Returns the node, or -1 when there is
+ * nothing to do (one node, no sysfs, an empty intersection).  venc_open calls it with scope 0 unless VENC_NUMA_BIND=0
+ * (VENC_NUMA_BIND=2: scope 1). */
+static int read_small_file(const char *path, char *buf, size_t cap) {
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    const size_t n = fread(buf, 1, cap - 1, f);
+    fclose(f);
+    buf[n] = 0;
+    return (int)n;
+}
+extern "C" int venc_numa_bind(int device, int scope) {
+    char bdf[64] = {0}, path[160], buf[4096];
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess) return -1;
+    for (char *p = bdf; *p; p++)
+        if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a'); /* sysfs spells bus ids in lower case */
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    if (read_small_file(path, buf, sizeof(buf)) <= 0) return -1;
+    const int node = atoi(buf);
+    if (node < 0) return -1;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    if (read_small_file(path, buf, sizeof(buf)) <= 0) return -1;
+    cpu_set_t want, have;
+    CPU_ZERO(&want);
+    for (char *p = buf; *p;) { /* "0-63,128-191" */
+        char *e;
+        const long a = strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') b = strtol(e + 1, &e, 10);
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++) CPU_SET((int)k, &want);
+        p = *e == ',' ? e + 1 : e;
+        if (*e != ',' ) break;
+    }
+    if (sched_getaffinity(0, sizeof(have), &have) != 0) return -1;
+    int n_have = 0, n_both = 0;
+    for (int k = 0; k < CPU_SETSIZE; k++) {
+        if (CPU_ISSET(k, &have)) n_have++;
+        if (CPU_ISSET(k, &have) && CPU_ISSET(k, &want)) n_both++; else CPU_CLR(k, &want);
+    }
+    if (n_both == 0 || n_both == n_have) return n_both ? node : -1; /* nothing allowed on that node / already there */
+    if (scope == 0) return sched_setaffinity(0, sizeof(want), &want) == 0 ? node : -1;
+    DIR *d = opendir("/proc/self/task");
+    if (!d) return sched_setaffinity(0, sizeof(want), &want) == 0 ? node : -1;
+    int ok = 0;
+    for (struct dirent *e; (e = readdir(d)) != NULL;) {
+        const int tid = atoi(e->d_name);
+        if (tid > 0 && sched_setaffinity(tid, sizeof(want), &want) == 0) ok++;
+    }
+    closedir(d);
+    return ok ? node : -1;
 }
 
 static void rccl_release(venc_ctx *c);
@@ -449,6 +510,10 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
         return -1;
     }
     HIP_OK(hipSetDevice(cfg->device));
+    {   /* the calling thread -- which launches every kernel of this context -- and the threads created from here on: beside the card */
+        const int nb = getenv("VENC_NUMA_BIND") ? atoi(getenv("VENC_NUMA_BIND")) : 1;
+        if (nb > 0) (void)venc_numa_bind(cfg->device, nb >= 2 ? 1 : 0);
+    }
     venc_ctx *c = (venc_ctx *)calloc(1, sizeof(venc_ctx));
     if (!c) return -1;
     c->cfg = *cfg;
@@ -700,7 +765,10 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     }
     c->me_stop = getenv("VENC_ME_STOP") ? atoi(getenv("VENC_ME_STOP")) : 0;
     c->me_fast = getenv("VENC_ME_FAST") ? atoi(getenv("VENC_ME_FAST")) : 1;
-    c->me_xcd = getenv("VENC_ME_XCD") && atoi(getenv("VENC_ME_XCD")) != 0;
+    /* XCD-aware tile order of the search (runs of 64 tiles dealt to the eight XCDs in rotation: a tile's neighbours share an L2).  Default from
+     * 200 000 macroblocks per step (2160p x 10 items: 223.4 - 225.6 -> 228.3 - 231.6 Gpx/s in three same-box A/Bs of round 4; at 1080p x 10 the
+     * launch gets 5 - 8 % longer and the pass does not change); whole pictures only (a band's search may go as two launches) */
+    c->me_xcd = getenv("VENC_ME_XCD") ? atoi(getenv("VENC_ME_XCD")) != 0 : (long long)g.nmb * cfg->max_items >= 200000;
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     if (cfg->deblock && (c->me_mode != 0 || c->inter_legacy || (getenv("VENC_INTRA") && !strcmp(getenv("VENC_INTRA"), "legacy")))) {
         SET_ERR("venc_open: the in-loop filter runs behind the shipped kernels only (VENC_ME / VENC_INTER / VENC_INTRA select test kernels)");
@@ -1144,7 +1212,8 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
              * tile count padded to whole rounds of eight runs (see k_me_pool) */
             const int runs = (ntx * nty + 63) / 64;
             const uint32_t tx_magic = ntx > 1 ? (uint32_t)((0x100000000ull + (uint64_t)ntx - 1) / (uint64_t)ntx) : 0u;
-            const int gx = c->me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
+            const int me_xcd = c->me_xcd && !c->rc_comm && c->band_s0 == 0 && c->band_s1 == c->g.n_slices;
+            const int gx = me_xcd ? 8 * 64 * ((runs + 7) / 8) : ntx * nty;
             /* (VENC_ME_LDS_PAD=bytes of unused dynamic LDS per block: an experiment that holds the search at two blocks per CU) */
             static const int lds_pad = getenv("VENC_ME_LDS_PAD") ? atoi(getenv("VENC_ME_LDS_PAD")) : 0;
             /* k_me_pool4 (venc_me4.hip): the same search laid out for four blocks per CU; it transforms in the deferred form only */
@@ -1160,7 +1229,7 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             S.tile0 = S.tile1 = 0;
             S.tile_split = S.tile_n = ntx * nty;
             const bool has_up = S.row0 > 0, has_dn = S.row1 < g.mbh;
-            const bool x_split = c->x_pending && pool4 && !two && !c->me_xcd && (has_up || has_dn) && nty >= 3;
+            const bool x_split = c->x_pending && pool4 && !two && !me_xcd && (has_up || has_dn) && nty >= 3;
             if (c->x_pending && !x_split) {
                 HIP_OK(hipStreamWaitEvent(s1, c->ev_x_done, 0));
                 c->x_pending = 0;
@@ -1186,13 +1255,13 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
                 hipStream_t sh = half ? c->stream_b : s1;
                 if (half) prof_end(c, s1); /* (the timed launches are the main stream's: half the items) */
                 if (pool4 && c->cfg.rc_mode)
-                    hipLaunchKernelGGL(k_me_pool4<true>, dim3(gxp, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                    hipLaunchKernelGGL(k_me_pool4<true>, dim3(gxp, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, me_xcd, fuse_arg);
                 else if (pool4)
-                    hipLaunchKernelGGL(k_me_pool4<false>, dim3(gxp, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                    hipLaunchKernelGGL(k_me_pool4<false>, dim3(gxp, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, me_xcd, fuse_arg);
                 else if (c->cfg.rc_mode)
-                    hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                    hipLaunchKernelGGL(k_me_pool<true>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, me_xcd, fuse_arg);
                 else
-                    hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, c->me_xcd, fuse_arg);
+                    hipLaunchKernelGGL(k_me_pool<false>, dim3(gx, 1, nh), dim3(512), (size_t)lds_pad, sh, g, b, Sh, ntx, nty, tx_magic, me_xcd, fuse_arg);
             }
             }
             S.tile0 = S.tile1 = 0;
