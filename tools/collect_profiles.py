@@ -53,7 +53,7 @@ for a, b in (("me_phase_1080p.txt", "me_phase_1080p.txt"), ("valu_ubench.txt", "
              ("deblock_step_budget.txt", "deblock_step_budget.txt"), ("deblock_sq_counters.txt", "deblock_sq_counters.txt"),
              ("ifetch_ubench.txt", "ifetch_ubench.txt"), ("ab_search_variants.txt", "ab_search_variants.txt"), ("ab_deblock_kernels.txt", "ab_deblock_kernels.txt"),
              ("timeline_1080p.txt", "timeline_1080p.txt"), ("timeline_2160p.txt", "timeline_2160p.txt"), ("ab_launcher_1080p.txt", "ab_launcher_1080p.txt"),
-             ("ab_launcher_2160p.txt", "ab_launcher_2160p.txt"), ("ingest_split.txt", "ingest_split.txt")):
+             ("ab_launcher_2160p.txt", "ab_launcher_2160p.txt"), ("ingest_split.txt", "ingest_split.txt"), ("entropy_block_lifetimes_1080p.txt", "entropy_block_lifetimes_1080p.txt")):
     p = os.path.join(src, a)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, b)))

@@ -54,9 +54,11 @@ cut -c1-160 $O/bench_streams2.json
 timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --steps 3 --warmup 1 --gpus 2 --backend gloo --device 0 $Q --slices-steps 2 > $O/bench_streams2_torchrun.json 2> $O/bench_streams2_torchrun.err
 grep -o '"equals_one_rank_bitstream": [a-z]*' $O/bench_streams2.json $O/bench_streams2_torchrun.json
 # the round's same-box A/B runs (medians of three rounds in rotation)
-WL=1080p REPS=3 bash tools/ab_env.sh ${1:-final}/ab_1080 "VENC_ENTROPY_CUS=0" "VENC_ENTROPY_CUS=192" "VENC_CHAINS=2" "VENC_PRIO=1" "GPU_MAX_HW_QUEUES=8" > $O/ab_launcher_1080p.txt 2>&1
-WL=2160p STEPS=12 REPS=2 bash tools/ab_env.sh ${1:-final}/ab_2160 "VENC_ENTROPY_CUS=0" "VENC_ENTROPY_CUS=160" "VENC_ENTROPY_CUS=192" "VENC_CHAINS=2" > $O/ab_launcher_2160p.txt 2>&1
+WL=1080p REPS=3 STEPS=30 bash tools/ab_env.sh ${1:-final}/ab_1080 "VENC_NUMA_BIND=1" "VENC_NUMA_BIND=0" "VENC_ENTROPY_CUS=0" "VENC_ME_LDS_PAD=8192 VENC_ENTROPY_CUS=0" "VENC_ME_XCD=1" "VENC_CHAINS=2" > $O/ab_launcher_1080p.txt 2>&1
+WL=2160p STEPS=12 REPS=3 bash tools/ab_env.sh ${1:-final}/ab_2160 "VENC_ME_XCD=1" "VENC_ME_XCD=0" "VENC_ENTROPY_CUS=0" "VENC_ME_XCD=0 VENC_ENTROPY_CUS=0" > $O/ab_launcher_2160p.txt 2>&1
 cat $O/ab_launcher_1080p.txt $O/ab_launcher_2160p.txt
+[ -f video-encoder_amd/csrc/libvenc_hip_stamps.so ] && { VENC_HIP_LIB=libvenc_hip_stamps.so VENC_NO_OVERLAP=1 python tools/ent_stamps.py 1080p 2>/dev/null | grep -v amdgpu.ids > $O/entropy_block_lifetimes_1080p.txt; cat $O/entropy_block_lifetimes_1080p.txt; }
+./tools/h2d_ubench 2>/dev/null | grep "depth [12]" > $O/h2d_ubench.txt; HSA_ENABLE_SDMA=0 ./tools/h2d_ubench 2>/dev/null | grep "depth [12]" | sed 's/^/blit kernels (HSA_ENABLE_SDMA=0): /' >> $O/h2d_ubench.txt; cat $O/h2d_ubench.txt
 python tools/ingest_trace.py 2>&1 | grep -v "venc trace:  \|amdgpu.ids" > $O/ingest_split.txt; cat $O/ingest_split.txt
 fi
 for d in $O/pmcf_* $O/pmcw_* $O/stats_* $O/sq_1080p $O/sq_2160p $O/tl1080 $O/tl2160; do [ -d "$d" ] && find $d -name "*agent_info.csv" -delete; done
