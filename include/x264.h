@@ -171,7 +171,9 @@ typedef struct x264_picture_t {
 int x264_param_default_preset(x264_param_t *param, const char *preset, const char *tune);
 /* accepts NULL (:105, :403); only "baseline" (or NULL) is honoured, other known names are accepted and ignored */
 int x264_param_apply_profile(x264_param_t *param, const char *profile);
-/* NULL on failure (:408-412), including "no HIP device": there is no CPU fallback */
+/* NULL on failure (:408-412), including "no HIP device": there is no CPU fallback.  Side effect: the calling thread -- it launches the
+ * encoder's kernels from here on -- and the threads the encoder creates are restricted to the CPUs of the card's NUMA node
+ * (venc_numa_bind, venc_hip.h; VENC_NUMA_BIND=0 leaves the caller's affinity alone) */
 x264_t *x264_encoder_open(x264_param_t *param);
 /* 0 on success; planes live in pinned host memory so ingest is a single DMA (:415, :545-547) */
 int x264_picture_alloc(x264_picture_t *pic, int i_csp, int i_width, int i_height);

@@ -920,3 +920,28 @@ def test_x264_api_with_intra_modes_and_rate_control(venc, orc):
         ref = enc.encode(*f)
         assert got[t].payload == ref.data, "frame %d" % t
         assert dec.decode(got[t].payload) == 1 and np.array_equal(dec.planes()[0], enc.recon()[0])
+
+
+@pytest.mark.gpu
+def test_opening_an_engine_puts_the_thread_beside_the_card(venc, monkeypatch):
+    """venc_open restricts the opening thread to the CPUs of the card's NUMA node (sysfs) unless VENC_NUMA_BIND=0; venc_numa_bind
+    reports the node (-1: one node, no sysfs, or nothing to do) and never widens the set the thread started with."""
+    import os
+    before = os.sched_getaffinity(0)
+    try:
+        monkeypatch.setenv("VENC_NUMA_BIND", "0")
+        venc.Engine(176, 144, qp=30, n_slices=1, max_items=1, in_slots=2, out_slots=2).close()
+        assert os.sched_getaffinity(0) == before
+        monkeypatch.setenv("VENC_NUMA_BIND", "1")
+        venc.Engine(176, 144, qp=30, n_slices=1, max_items=1, in_slots=2, out_slots=2).close()
+        after = os.sched_getaffinity(0)
+        assert after and after <= before
+        node = venc.hip_lib().venc_numa_bind(0, 0)
+        if node >= 0 and os.path.exists("/sys/devices/system/node/node%d/cpulist" % node):
+            cpus = set()
+            for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus |= set(range(int(a), int(b or a) + 1))
+            assert os.sched_getaffinity(0) <= cpus
+    finally:
+        os.sched_setaffinity(0, before)
