@@ -332,29 +332,38 @@ __global__ __launch_bounds__(ENT_THREADS) void k_entropy_p(venc_geom g, venc_buf
             rank++;
         }
         /* the blocks: one with levels is listed for phase B (its table class beside it); the empty ones behind it ride on it: `tail` = their
-         * classes, two bits each from bit 0, the count in bits 16-18 (at most seven: a coded 8x8 block / chroma AC plane holds levels) */
-        uint32_t tail = 0, prev_pos = 0xffffffffu;
-        while (blocks) {
-            const int bq = __builtin_ctz(blocks);
-            blocks &= blocks - 1u;
-            const uint32_t c = (uint32_t)(cw >> (2 * bq)) & 3u;
-            if ((lev >> bq) & 1u) {
-                if (prev_pos != 0xffffffffu) {
-                    if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;
-                }
-                tail = 0;
-                const uint32_t rec = (rank << 18) | ((bq == 16 || bq == 17 ? 0u : 1u + (c == 0u ? 0u : c == 1u ? 2u : c == 2u ? 4u : 8u)) << 13) | ((uint32_t)tid << 5) | (uint32_t)(bq + 2);
-                const uint32_t pos_n = (sm >> (bq + 2)) & 1u ? pos_s++ : pos_m++;
-                if (pos_n < ENT_CLS_LDS) s_cls[pos_n] = rec; else cls_mem[pos_n] = rec;
-                prev_pos = pos_n;
-                rank++;
+         * classes, two bits each from bit 0, the count in bits 16-18 (at most seven: a coded 8x8 block / chroma AC plane holds levels).
+         * The loop visits the blocks WITH levels only (a walk over every present block cost ~70 instructions per block, twenty-four
+         * times in most waves): a block's riders are the present blocks below the next block with levels -- the rest of its own group
+         * of four and the head of that next block's group, i.e. at most two runs of consecutive bits (groups in between are absent as
+         * a whole; the eight chroma AC blocks are all present or all absent) -- and their classes two shifts of the class word. */
+        uint32_t L = lev & blocks;
+        while (L) {
+            const int bq = __builtin_ctz(L);
+            L &= L - 1u;
+            const uint32_t above = blocks & (0xfffffffeu << bq);
+            const uint32_t rm = L ? above & ((1u << __builtin_ctz(L)) - 1u) : above;
+            const int s1 = __builtin_ctz(rm | 0x80000000u); /* (no rider: 31, and everything below comes out empty) */
+            const int l1 = __builtin_ctz(~(rm >> s1));
+            const uint32_t rm2 = rm & ~(((1u << l1) - 1u) << s1);
+            const int s2 = __builtin_ctz(rm2 | 0x80000000u), l2 = __popc(rm2);
+            const uint32_t f1 = (uint32_t)(cw >> (2 * s1)) & ((1u << (2 * l1)) - 1u), f2 = (uint32_t)(cw >> (2 * s2)) & ((1u << (2 * l2)) - 1u);
+            const uint32_t tail = f1 | (f2 << (2 * l1)) | ((uint32_t)(l1 + l2) << 16);
+            const uint32_t c4 = 4u * ((uint32_t)(cw >> (2 * bq)) & 3u);
+            const uint32_t ncf = (bq == 16 || bq == 17) ? 0u : (0x9531u >> c4) & 15u; /* nC + 1 of the class: 1, 3, 5, 9; the chroma DC blocks: 0 */
+            const uint32_t rec = (rank << 18) | (ncf << 13) | ((uint32_t)tid << 5) | (uint32_t)(bq + 2);
+            const bool one = (sm >> (bq + 2)) & 1u;
+            const uint32_t pos_n = one ? pos_s : pos_m;
+            pos_s += one ? 1u : 0u;
+            pos_m += one ? 0u : 1u;
+            if (pos_n < ENT_CLS_LDS) {
+                s_cls[pos_n] = rec;
+                s_cls2[pos_n] = tail;
             } else {
-                const uint32_t n = tail >> 16;
-                tail = (tail & 0xffffu) | (c << (2u * n)) | ((n + 1u) << 16);
+                cls_mem[pos_n] = rec;
+                cls2_mem[pos_n] = tail;
             }
-        }
-        if (prev_pos != 0xffffffffu) {
-            if (prev_pos < ENT_CLS_LDS) s_cls2[prev_pos] = tail; else cls2_mem[prev_pos] = tail;
+            rank++;
         }
     }
     ENT_STAMP(2);
