@@ -99,10 +99,19 @@ class EnginePort:
     def import_(self, engine, n_items, chunk, item_stride, slice_first, slice_count, halo_rows):
         engine.band_import(n_items, chunk.data_ptr(), item_stride, slice_first, slice_count, halo_rows)
 
+    def xbegin(self, engine):
+        """export / import until xend() go to the engine's exchange stream; the next P step launches the tile rows that read no
+        neighbour's row beside them and the band's edge rows behind them (include/venc_hip.h venc_band_xbegin)"""
+        engine.band_xbegin()
+
+    def xend(self, engine):
+        engine.band_xend()
+
     def stream(self, engine):
-        """The engine's main HIP stream as a torch stream: collectives issued under it are ordered with the
-        engine's kernels (ProcessGroupNCCL syncs its own stream with the current one on both sides)."""
-        h = engine.stream_handle()
+        """The stream band copies belong on right now (the exchange stream between xbegin and xend, else the main stream) as a
+        torch stream: collectives issued under it are ordered with the engine's kernels (ProcessGroupNCCL syncs its own stream
+        with the current one on both sides)."""
+        h = engine.band_stream()
         if self._stream is None or self._stream_handle != h:
             self._stream = self.torch.cuda.ExternalStream(h, device=self.device)
             self._stream_handle = h
@@ -154,6 +163,9 @@ class BandExchange:
             return
         send, recv = self._buffers(engine, n_items)
         per_rank = self._stride * self._items
+        xbegin, xend = getattr(self.port, "xbegin", None), getattr(self.port, "xend", None)
+        if xbegin:
+            xbegin(engine)
         self.port.export(engine, n_items, send, self._stride, self.halo_rows)
         on_device = send.is_cuda and dist.get_backend(self.group) == "nccl"
         if on_device:
@@ -170,6 +182,8 @@ class BandExchange:
             s0, cnt = self.bands[r]
             self.port.import_(engine, n_items, recv[r * per_rank:(r + 1) * per_rank], self._stride, s0, cnt,
                               self.halo_rows)
+        if xend:
+            xend(engine)
         self.exchanges += 1
 
 
