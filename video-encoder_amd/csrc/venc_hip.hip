@@ -1274,7 +1274,10 @@ extern "C" int venc_encode_step(venc_ctx *c, int n_items, const int *in_slots, c
             prof_begin(c, KID_MEFIX, s1);
             /* the blocks that code the 4x4 blocks P5 listed, first in dispatch order: per item one per NZ_RPB segments, each takes an
              * equal share of the item's entries; every thread of such a block reads nz_rpt segment counts (a multiple of four) */
-            static const int nz_rpb = getenv("VENC_NZ_RPB") ? atoi(getenv("VENC_NZ_RPB")) : NZ_RPB;
+            /* (about sixteen follow-up blocks per item: NZ_RPB = 128 segments per block up to 1080p; at 2160p -- 8100 segments -- 256 or 512 per
+             * block shorten the launch from 26.4 to 24.0 us and the pass by 1 %, 64 or 1024 lengthen it to 31 - 32: r04_rpb) */
+            static const int nz_rpb_env = getenv("VENC_NZ_RPB") ? atoi(getenv("VENC_NZ_RPB")) : 0;
+            const int nz_rpb = nz_rpb_env > 0 ? nz_rpb_env : (nz_regions + 15) / 16 > NZ_RPB ? (((nz_regions + 15) / 16 + 3) & ~3) : NZ_RPB;
             const int nz_blocks = (nz_regions + nz_rpb - 1) / nz_rpb;
             const int nz_rpt = (((nz_regions + 64 * FIX_WAVES - 1) / (64 * FIX_WAVES)) + 3) & ~3;
             const size_t fix_lds = nz_blocks ? (size_t)64 * FIX_WAVES * nz_rpt : 0;
