@@ -945,3 +945,33 @@ def test_opening_an_engine_puts_the_thread_beside_the_card(venc, monkeypatch):
             assert os.sched_getaffinity(0) <= cpus
     finally:
         os.sched_setaffinity(0, before)
+
+
+@pytest.mark.gpu
+def test_frames_come_back_a_unit_and_a_half_behind_the_input(venc):
+    """With G GOPs in lock-step a frame is handed back G x keyint x 1.5 calls after it went in (include/x264.h: a unit is launched when its
+    last picture has arrived, half a unit more covers its time on the GPU), in display order, and the flush loop drains the rest."""
+    w, h, keyint, g, n = 176, 144, 4, 2, 40
+    frames = [venc.synth_frame(w, h, t) for t in range(n)]
+    e = venc.X264Encoder(w, h, qp=28, slices=2, keyint=keyint, gop_batch=g)
+    unit, first = g * keyint, None
+    out = []
+    for t, (y, u, v) in enumerate(frames):
+        r = e.encode(y, u, v, t)
+        if r is not None:
+            first = t if first is None else first
+            out.append(r)
+    assert first == unit + unit // 2
+    assert e.delayed_frames() == n - len(out) == unit + unit // 2
+    out += e.flush()
+    e.close()
+    assert [f.pts for f in out] == list(range(n)) and all(f.keyframe == (f.pts % keyint == 0) for f in out)
+    ref = venc.X264Encoder(w, h, qp=28, slices=2, keyint=keyint, gop_batch=1)
+    want = []
+    for t, (y, u, v) in enumerate(frames):
+        r = ref.encode(y, u, v, t)
+        if r is not None:
+            want.append(r)
+    want += ref.flush()
+    ref.close()
+    assert [f.payload for f in out] == [f.payload for f in want]
