@@ -329,3 +329,32 @@ def test_register_head_bit_sink_equals_the_plain_sink(hc):
                         assert not words[nw:32].any()  # nothing beyond the string (the pack kernel ORs whole words)
                         spilled += nw > 4
     assert spilled > 20
+
+
+def test_search_key_orders_like_the_rank_table():
+    """k_me_pool4 keeps a macroblock's running best as ONE dword, SAD << 13 | (|dx| + |dy|) << 7 | cy << 1 | (dx > 0)
+    (venc_me4.hip me4_key), where the other search kernels and the oracle order by (SAD, rank), rank = index of the
+    displacement in the list sorted by (|dx| + |dy|, dy, dx) (venc_hip.hip, the table behind venc_bufs.me_rank).  Python
+    model of both: the tie-break field must sort all 33 x 33 displacements exactly as the rank does, be unique, fit 13 bits,
+    and give the displacement back (me4_key_disp)."""
+    R = 16
+    disps = sorted(((abs(dx) + abs(dy), dy, dx) for dy in range(-R, R + 1) for dx in range(-R, R + 1)))
+    rank = {(dx, dy): i for i, (_, dy, dx) in enumerate(disps)}
+
+    def key(sad, cx, cy):
+        l1 = abs(cx - 16) + abs(cy - 16)
+        return (sad << 13) | (l1 << 7) | (cy << 1) | (1 if cx > 16 else 0)
+
+    def disp(k):
+        cy, l1 = (k >> 1) & 63, (k >> 7) & 63
+        a = l1 - abs(cy - 16)
+        return (16 + a if k & 1 else 16 - a), cy
+
+    ties = {}
+    for (dx, dy), r in rank.items():
+        t = key(0, dx + 16, dy + 16)
+        assert t < (1 << 13) and t not in ties
+        ties[t] = r
+        assert disp(key(12345, dx + 16, dy + 16)) == (dx + 16, dy + 16)
+    assert [ties[t] for t in sorted(ties)] == list(range(33 * 33))
+    assert key(255 * 256, 32, 32) < (1 << 32) and key(7, 0, 0) < key(8, 16, 16)  # the SAD dominates; the largest key fits

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$1; F=$2; shift 2
 mkdir -p $O; cd $R
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for v in "$@"; do
     VENC_HIP_LIB=$v timeout -k 10 200 python bench.py --no-extras --cpu-frames 0 --steps 10 $F > $O/${v%.so}_$rep.json 2> $O/${v%.so}_$rep.err || { echo "$v FAILED"; tail -3 $O/${v%.so}_$rep.err; exit 1; }
     python3 - "$O/${v%.so}_$rep.json" "$v" <<'PY'

@@ -16,8 +16,8 @@
  *     three slots: six dword reads for four candidate rows (venc_me3: eight), two extra vector instructions for two of them.
  *  2. P2 has less to do: four segments of sixteen rows x 78 column pairs, eight pair stores each (venc_me3: six segments of
  *     seventeen rows with nine stores).
- *  3. THE RANK TABLE STAYS IN MEMORY (2.2 KB of LDS): it is read for the start points and once per evaluated survivor, each
- *     time ahead of a SAD that hides the load.
+ *  3. NO RANK TABLE (2.2 KB of LDS in venc_me3; read from memory here until round 4): the running best is a 32-bit key that
+ *     carries the search's tie-break order itself (me4_key below).
  *  4. THE SECOND PASS KEEPS NO BOUNDS.  A wave whose start points were poor used to keep the 33 packed bounds of every lane
  *     (33 registers) to find the smallest one and to re-test them; here it finds the smallest in one pass of running minima
  *     and then simply runs the fast pass again against the tighter threshold -- the rare path pays twice for its bounds, the
@@ -36,6 +36,21 @@ DEVFN uint32_t me4_bound(uint32_t l, uint32_t r, uint32_t cleft, uint32_t cright
 DEVFN uint32_t me4_mid(uint32_t next, uint32_t cur) { /* high half of cur | low half of next << 16 */
     return __builtin_amdgcn_alignbit(next, cur, 16u);
 }
+/* THE RUNNING BEST IS ONE DWORD.  The search's order is (SAD, |dx| + |dy|, dy, dx) -- the rank table (venc_hip.hip) is the sort
+ * index of its last three terms.  Given |dx| + |dy| and dy, dx is known up to its sign: SAD << 13 | (|dx| + |dy|) << 7 | cy << 1 |
+ * (dx > 0) orders the candidates exactly as (SAD << 11 | rank) does, is unique, holds the displacement itself and fits 29 bits
+ * (SAD <= 255 * 256 < 2^16): no rank load in front of a key (the one per evaluated survivor sat exposed at the tail of every
+ * block), a 32-bit ds_min instead of a 64-bit one, no 64-bit shifts. */
+DEVFN uint32_t me4_key(uint32_t sad, uint32_t cx, uint32_t cy) {
+    const uint32_t l1 = __builtin_amdgcn_sad_u8(cx | (cy << 8), 0x1010u, 0u);
+    return (sad << 13) | (l1 << 7) | (cy << 1) | (cx > 16u ? 1u : 0u);
+}
+DEVFN void me4_key_disp(uint32_t key, uint32_t &cx, uint32_t &cy) {
+    cy = (key >> 1) & 63u;
+    const uint32_t l1 = (key >> 7) & 63u;
+    const uint32_t a = l1 - __builtin_amdgcn_sad_u8(cy, 16u, 0u);
+    cx = (key & 1u) ? 16u + a : 16u - a;
+}
 
 template <bool RC>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_me_pool4(venc_geom g, venc_bufs B, venc_step S, int tiles_x, int tiles_y, uint32_t tx_magic, int xcd_runs, int fuse_luma) {
@@ -44,7 +59,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     /* horizontal sums (P1 -> P2), then, after a barrier, the vertical pairs built from them (P2 -> P4a): the same 19968 bytes */
     __shared__ __attribute__((aligned(16))) uint4 s_hv[T4_VS * T2_HG];
     __shared__ uint32_t s_pool[T3_POOL];
-    __shared__ __attribute__((aligned(8))) unsigned long long s_best[T2_MBX * T2_MBY];
+    __shared__ uint32_t s_best[T2_MBX * T2_MBY]; /* me4_key of the best candidate so far */
     __shared__ uint32_t s_ovf[T2_MBX * T2_MBY];
     __shared__ __attribute__((aligned(16))) uint32_t s_wcnt[8];
     __shared__ uint32_t s_prev[T2_MBX * T2_MBY];
@@ -58,7 +73,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int lane = tid & 63, l32 = lane & 31, hbase = lane & 32, hw = tid >> 5;
     const int mbx = hw & (T2_MBX - 1), mby = hw >> 3;
     const int col0 = mbx * 16, row0 = mby * 16;
-    const uint16_t *rank = B.me_rank;
     const int item = (int)blockIdx.z + S.item0;
     const int kx = (int)(blockIdx.x >> 3);
     const int tile_l = xcd_runs ? ((((kx >> 6) << 3) + (int)(blockIdx.x & 7u)) << 6) + (kx & 63) : (int)blockIdx.x;
@@ -139,9 +153,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
     if (S.me_stop == 1) return;
-    /* ---- P1: horizontal 8-sums (as venc_me3) + the four 8x8 sums of every current macroblock ---- */
+    /* ---- P1: horizontal 8-sums (as venc_me3) ---- */
     {
-        const int r = tid >> 3, q0 = (tid & 7) * 5;
+        /* lane = window row, wave = five of the forty column groups: a half-wave's dword reads fall on sixteen banks twice over (rows 42
+         * dwords apart) and its 8-byte stores on all of them; with eight threads along a row and the rows across the wave the reads were
+         * four to a bank (60 % of this phase's LDS cycles were conflicts) */
+        const int r = tid & 63, q0 = (tid >> 6) * 5;
         const uint32_t *p = s_win + r * T2_WD + q0;
         uint32_t dwd[7];
 #pragma unroll
@@ -155,18 +172,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
         for (int k = 0; k < 5; k++)
             if (q0 + k < T2_HG) s_h8[r * T2_HG + q0 + k] = pk4_add(h4[k], h4[k + 1]);
-        if (tid < 2 * T2_MBX * T2_MBY) {
-            const int m = tid >> 1, half = tid & 1;
-            const uint32_t *cp = s_cur + ((m >> 3) * 16) * T3_CW + (m & (T2_MBX - 1)) * 4 + half * 2;
-            uint32_t top = 0, bot = 0;
-#pragma unroll
-            for (int y = 0; y < 8; y++) {
-                const uint2 a = *(const uint2 *)(cp + y * T3_CW), bq = *(const uint2 *)(cp + (y + 8) * T3_CW);
-                top = __builtin_amdgcn_sad_u8(a.y, 0u, __builtin_amdgcn_sad_u8(a.x, 0u, top));
-                bot = __builtin_amdgcn_sad_u8(bq.y, 0u, __builtin_amdgcn_sad_u8(bq.x, 0u, bot));
-            }
-            s_c8[m][half] = top | (bot << 16);
-        }
     }
     __syncthreads();
     if (S.me_stop == 2) return;
@@ -192,6 +197,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (k + 7 <= last) acc = acc + col[(k + 7) * 2 * T2_HG] - col[(k - 1) * 2 * T2_HG];
                 sr[k] = acc;
             }
+        } else if (tid >= 512 - 2 * T2_MBX * T2_MBY) {
+            /* the four 8x8 sums of every current macroblock, by half of the one wave this phase leaves idle (in P1, on wave 0, they
+             * doubled that wave's instruction stream and the block waited for it at the barrier) */
+            const int t = tid - (512 - 2 * T2_MBX * T2_MBY), m = t >> 1, half = t & 1;
+            const uint32_t *cp = s_cur + ((m >> 3) * 16) * T3_CW + (m & (T2_MBX - 1)) * 4 + half * 2;
+            uint32_t top = 0, bot = 0;
+#pragma unroll
+            for (int y = 0; y < 8; y++) {
+                const uint2 a = *(const uint2 *)(cp + y * T3_CW), bq = *(const uint2 *)(cp + (y + 8) * T3_CW);
+                top = __builtin_amdgcn_sad_u8(a.y, 0u, __builtin_amdgcn_sad_u8(a.x, 0u, top));
+                bot = __builtin_amdgcn_sad_u8(bq.y, 0u, __builtin_amdgcn_sad_u8(bq.x, 0u, bot));
+            }
+            s_c8[m][half] = top | (bot << 16);
         }
         __syncthreads();
         if (act) {
@@ -199,7 +217,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const uint32_t lo = sr[j], hi = sr[j + 8];
-                *(uint2 *)(dst + j * T2_SU) = make_uint2((lo & 0xffffu) | (hi << 16), (lo >> 16) | (hi & 0xffff0000u));
+                *(uint2 *)(dst + j * T2_SU) = make_uint2(__builtin_amdgcn_perm(hi, lo, 0x05040100u), __builtin_amdgcn_perm(hi, lo, 0x07060302u)); /* lo.lo | hi.lo << 16, lo.hi | hi.hi << 16: one v_perm each */
             }
         }
     }
@@ -212,21 +230,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const uint32_t prev = s_prev[hw];
     /* ---- P3: two start points per macroblock (last frame's vector | the zero vector), as venc_me3 ---- */
     const int pcx = (int)(int8_t)(prev & 255u) + 16, pcy = (int)(int8_t)((prev >> 8) & 255u) + 16;
-    const int ci_p = pcy * 33 + pcx, ci_z = 16 * 33 + 16;
+    const int ci_p = (pcy << 6) | pcx, ci_z = (16 << 6) | 16; /* candidate = cy << 6 | cx in the pool's entries */
     uint32_t thr;
     {
         const bool second = (lane & 16) != 0;
-        const uint32_t rank_p = rank[ci_p], rank_z = rank[ci_z]; /* from memory: issued before the SAD, used after it */
         const uint32_t a = me3_quarter_sad(s_win, s_cur, col0, row0, lane, second ? 16 : pcx, second ? 16 : pcy);
         const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), q1 = (uint32_t)__builtin_amdgcn_readlane((int)a, 31);
         const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47), q3 = (uint32_t)__builtin_amdgcn_readlane((int)a, 63);
         const uint32_t sad_p = lane < 32 ? q0 : q2, sad_z = lane < 32 ? q1 : q3;
         thr = min(sad_p, sad_z);
-        if (l32 == 0) {
-            const unsigned long long kp = ((unsigned long long)((sad_p << 11) | rank_p) << 11) | (uint32_t)ci_p;
-            const unsigned long long kz = ((unsigned long long)((sad_z << 11) | rank_z) << 11) | (uint32_t)ci_z;
-            s_best[hw] = kp < kz ? kp : kz;
-        }
+        if (l32 == 0) s_best[hw] = min(me4_key(sad_p, (uint32_t)pcx, (uint32_t)pcy), (sad_z << 13) | (16u << 1));
     }
     if (S.me_stop == 4) {
         if (l32 == 0 && mb_valid) B.mvsad[(size_t)item * g.nmb + (size_t)my * g.mbw + mx] = thr << 16;
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
      * candidate with the smallest bound, evaluates it as a third start point and runs the pass again. ---- */
     uint32_t mycnt = 0;
     {
-        const uint32_t tag = (uint32_t)hw << 11;
+        const uint32_t tag = (uint32_t)hw << 12; /* entry = LB << 16 | macroblock << 12 | cy << 6 | cx (LB <= 4 * 64 * 255 < 2^16) */
         const uint32_t lt = (1u << l32) - 1u;
         uint32_t *seg = s_pool + (tid >> 6) * (2 * T3_CAP);
         uint32_t wcnt = 0;
@@ -274,11 +287,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             uint32_t opq = 0; /* (an offset, not the pointer: through the asm a pointer loses its LDS address space and the reads turn flat) */
             asm volatile("" : "+v"(opq));
             const uint32_t *colp = colp0 + opq;
+            uint32_t nx[6] = {colp[0], colp[8], colp[8 * T2_SU], colp[8 * T2_SU + 8], colp[16 * T2_SU], colp[16 * T2_SU + 8]};
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint32_t l0 = colp[j * T2_SU], r0 = colp[j * T2_SU + 8];
-                const uint32_t l1 = colp[(j + 8) * T2_SU], r1 = colp[(j + 8) * T2_SU + 8];
-                const uint32_t l2 = colp[(j + 16) * T2_SU], r2 = colp[(j + 16) * T2_SU + 8];
+                /* the next group's six dwords are on their way while this group is tested (a group's reads used to be issued behind the
+                 * previous group's branch: every group began with an LDS round trip) */
+                const uint32_t l0 = nx[0], r0 = nx[1], l1 = nx[2], r1 = nx[3], l2 = nx[4], r2 = nx[5];
+                if (j < 7) {
+                    nx[0] = colp[(j + 1) * T2_SU], nx[1] = colp[(j + 1) * T2_SU + 8];
+                    nx[2] = colp[(j + 9) * T2_SU], nx[3] = colp[(j + 9) * T2_SU + 8];
+                    nx[4] = colp[(j + 17) * T2_SU], nx[5] = colp[(j + 17) * T2_SU + 8];
+                }
                 uint32_t lb[5];
                 lb[0] = me4_bound(l0, r0, cleft, cright);                           /* cy = j */
                 lb[1] = me4_bound(me4_mid(l1, l0), me4_mid(r1, r0), cleft, cright); /* cy = j + 8 */
@@ -296,8 +315,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                          * loop invariants, the 33 candidate indices, pool entries and start-point compares cost 60+ registers) */
                         uint32_t lx = (uint32_t)l32;
                         asm volatile("" : "+v"(lx));
-                        const uint32_t ci = (uint32_t)((j + 8 * t) * 33) + lx;
-                        append(hit && ci != (uint32_t)ci_p && ci != (uint32_t)ci_z && ci != (uint32_t)ai, (lb[t] << 15) | tag | ci);
+                        const uint32_t ci = (uint32_t)((j + 8 * t) << 6) + lx;
+                        append(hit && ci != (uint32_t)ci_p && ci != (uint32_t)ci_z && ci != (uint32_t)ai, (lb[t] << 16) | tag | ci);
                     }
                 }
             }
@@ -306,9 +325,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 if (__ballot(hit0 || hit1) != 0ull) {
                     uint32_t lx = (uint32_t)l32;
                     asm volatile("" : "+v"(lx));
-                    const uint32_t ci0 = lx * 33u + 32u, ci1 = (uint32_t)(32 * 33 + 32);
-                    append(hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ci_z && ci0 != (uint32_t)ai, (lbx0 << 15) | tag | ci0);
-                    append(hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ci_z && ci1 != (uint32_t)ai, (lbx1 << 15) | tag | ci1);
+                    const uint32_t ci0 = (lx << 6) + 32u, ci1 = (uint32_t)((32 << 6) + 32);
+                    append(hit0 && ci0 != (uint32_t)ci_p && ci0 != (uint32_t)ci_z && ci0 != (uint32_t)ai, (lbx0 << 16) | tag | ci0);
+                    append(hit1 && ci1 != (uint32_t)ci_p && ci1 != (uint32_t)ci_z && ci1 != (uint32_t)ai, (lbx1 << 16) | tag | ci1);
                 }
             }
             if (!first_pass) break;
@@ -333,18 +352,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (l32 == 0) m = min(m, (lbx1 << 12) | (32u << 6) | 32u);
             const uint32_t wmin = half_min32(m, lane);
             const int acy = (int)((wmin >> 6) & 63u), acx = (int)(wmin & 63u);
-            ai = acy * 33 + acx;
+            ai = (int)(wmin & 4095u);
             {
-                const uint32_t rank_a = rank[ai];
                 const uint32_t a = me3_quarter_sad(s_win, s_cur, col0, row0, lane, acx, acy); /* both quarters of a half: the same candidate */
                 const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)a, 15), q2 = (uint32_t)__builtin_amdgcn_readlane((int)a, 47);
                 const uint32_t sad_a = lane < 32 ? q0 : q2;
                 thr = min(thr, sad_a);
-                if (l32 == 0) {
-                    const unsigned long long ka = ((unsigned long long)((sad_a << 11) | rank_a) << 11) | (uint32_t)ai;
-                    const unsigned long long cur_best = s_best[hw];
-                    s_best[hw] = ka < cur_best ? ka : cur_best;
-                }
+                if (l32 == 0) s_best[hw] = min(s_best[hw], me4_key(sad_a, (uint32_t)acx, (uint32_t)acy));
             }
             wcnt = 0, mycnt = 0; /* the segment is rebuilt */
         }
@@ -357,10 +371,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     }
     __syncthreads();
     if (S.me_stop == 5) {
-        if (l32 == 0 && mb_valid) B.mvsad[(size_t)item * g.nmb + (size_t)my * g.mbw + mx] = (uint32_t)(s_best[hw] >> 22) << 16;
+        if (l32 == 0 && mb_valid) B.mvsad[(size_t)item * g.nmb + (size_t)my * g.mbw + mx] = (s_best[hw] >> 13) << 16;
         return;
     }
-    /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves (as venc_me3; ranks from memory) ----
+    /* ---- P4b: the tile's survivors, round-robin over the block's 32 quarter-waves (as venc_me3) ----
      * From here on the lane indices are re-derived from an opaque copy of the thread id: carried across P4a, four of them were
      * spilled (scratch stores and reloads of every thread: 42 MB of writes per 1080p launch in the PMC counters, and a memory round
      * trip at the head of every block's tail). */
@@ -385,15 +399,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             }
             const bool found = k < total;
             const uint32_t e = found ? s_pool[sbase + (k - start)] : 0xffffffffu;
-            const int ehw = (int)((e >> 11) & 15u), ci = (int)(e & 2047u);
-            bool need = found;
-            if (need) need = s_ovf[ehw] <= (uint32_t)T3_CAP && (e >> 15) <= (uint32_t)(s_best[ehw] >> 22);
+            const int ehw = (int)((e >> 12) & 15u);
+            const uint32_t eov = s_ovf[ehw], ebest = s_best[ehw]; /* (both reads in flight together; a lane without an entry reads macroblock 15's) */
+            const bool need = found && eov <= (uint32_t)T3_CAP && (e >> 16) <= (ebest >> 13);
             if (__ballot(need) == 0ull) continue;
-            const uint32_t rk = rank[need ? ci : 0];
-            const int cy = need ? ci / 33 : 16, cx = need ? ci - (ci / 33) * 33 : 16;
+            const int cy = need ? (int)((e >> 6) & 63u) : 16, cx = need ? (int)(e & 63u) : 16;
             const int ecol = need ? (ehw & (T2_MBX - 1)) * 16 : 0, erow = need ? (ehw >> 3) * 16 : 0;
             const uint32_t sad = me3_quarter_sad(s_win, s_cur, ecol, erow, laneb, cx, cy);
-            if (need && (laneb & 15) == 15) atomicMin(&s_best[ehw], ((unsigned long long)((sad << 11) | rk) << 11) | (uint32_t)ci);
+            if (need && (laneb & 15) == 15) atomicMin(&s_best[ehw], me4_key(sad, (uint32_t)cx, (uint32_t)cy));
         }
     }
     __syncthreads();
@@ -403,11 +416,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int mxo = tx * T2_MBX + (m & (T2_MBX - 1)), myo = S.row0 + ty * T2_MBY + ((m >> 3) & (T2_MBY - 1));
         if (m < T2_MBX * T2_MBY && mxo < g.mbw && myo < S.row1) {
             const size_t mbo = (size_t)item * g.nmb + (size_t)myo * g.mbw + mxo;
-            const unsigned long long best = s_best[m];
+            const uint32_t best = s_best[m];
             const uint32_t cnt = s_ovf[m];
-            const uint32_t ci = (uint32_t)best & 2047u, bcy = ci / 33u;
-            const int dx = (int)(ci - bcy * 33u) - 16, dy = (int)bcy - 16;
-            B.mvsad[mbo] = ((uint32_t)(best >> 22) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
+            uint32_t bcx, bcy;
+            me4_key_disp(best, bcx, bcy);
+            const int dx = (int)bcx - 16, dy = (int)bcy - 16;
+            B.mvsad[mbo] = ((best >> 13) << 16) | (((uint32_t)dy & 255u) << 8) | ((uint32_t)dx & 255u);
             const bool overflow = cnt > T3_CAP;
             B.me_flag[mbo] = overflow ? 1 : 0;
             if (overflow) B.fix_list[(size_t)item * g.nmb + atomicAdd(&B.fix_count[item], 1u)] = (uint32_t)(myo * g.mbw + mxo);
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             uint32_t sad = 0;
             if (l7 < T2_MBX * T2_MBY) {
                 const int mx7 = tx * T2_MBX + (l7 & (T2_MBX - 1)), my7 = S.row0 + ty * T2_MBY + (l7 >> 3);
-                if (mx7 < g.mbw && my7 < S.row1) sad = (uint32_t)(s_best[l7] >> 22);
+                if (mx7 < g.mbw && my7 < S.row1) sad = s_best[l7] >> 13;
             }
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_incl(sad), 63);
             if (l7 == 0 && tot) atomicAdd(&B.sad_cur[item], (unsigned long long)tot);
@@ -435,7 +449,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int mcol0 = (m & (T2_MBX - 1)) * 16, mrow0 = (m >> 3) * 16;
         const int mx5 = tx * T2_MBX + (m & (T2_MBX - 1)), my5 = S.row0 + ty * T2_MBY + (m >> 3);
         const bool ok = mx5 < g.mbw && my5 < S.row1 && s_ovf[m] <= (uint32_t)T3_CAP;
-        const uint32_t ci = (uint32_t)s_best[m] & 2047u, bcy = ci / 33u, bcx = ci - bcy * 33u;
+        uint32_t bcx, bcy;
+        me4_key_disp(s_best[m], bcx, bcy);
         const int bx = blk_x(blk) * 4, by = blk_y(blk) * 4;
         const int boff = mcol0 + (int)bcx + bx;
         const uint32_t sh = (uint32_t)(boff & 3);

@@ -35,6 +35,8 @@
 #include "h264_syntax.h"
 
 #define SHIM_MAX_NALS (2 + 256)
+#define SHIM_MAX_HELPERS 6
+#define SHIM_HEAVY_STEP_BYTES ((size_t)128 << 10) /* a step's frames go to the helpers from this many payload bytes (VENC_PACK_HEAVY_KB): a unit's I pictures above all (5.6 MB at 1080p x 10 GOPs), and P steps of ten or more GOPs (270 KB there) */
 
 typedef struct {
     int64_t pts;
@@ -79,6 +81,19 @@ struct x264_t {
     pthread_cond_t cv_work, cv_done;
     volatile int64_t w_launched; /* copy of n_launched for the worker (under mtx) */
     volatile int w_stop, w_err;
+    /* ... and the frames of a HEAVY step (the unit's I pictures: 5.6 MB per 1080p unit, 1.1 ms on one thread, during which the
+     * packaging thread fell a dozen P steps behind the GPU and the unit's last frames reached the caller late) are shared with
+     * helper threads that sleep otherwise: the packaging thread lists the step's frames as a job, takes frames from it itself
+     * and waits for the last one.  Everything about a job is read and written under jmtx.  Same box, six runs each, 1080p x 10
+     * GOPs: packaging thread alone 180.2 Gpx/s (178.6 - 182.9), + 2 helpers on the I pictures 190.4 (190.2 - 191.2), + P steps
+     * shared too 191.6; 2160p the same with and without (244): gpurun_out/r04_s3f. */
+    pthread_t helper[SHIM_MAX_HELPERS];
+    int n_helpers;
+    pthread_mutex_t jmtx;
+    pthread_cond_t jcv_work, jcv_done;
+    int64_t j_frames[64]; /* (at most 64 items advance in lock-step) */
+    int j_n, j_next, j_done, j_err, j_gen, j_stop;
+    size_t heavy_bytes;
 };
 
 /* slice-parallel mode: let the bands' owners swap reconstructed rows before the next P picture */
@@ -96,6 +111,7 @@ static double now_ms(void) {
 }
 
 static void *packaging_thread(void *arg);
+static void *packaging_helper(void *arg);
 
 static const char *const k_presets[] = {"ultrafast", "superfast", "veryfast", "faster", "fast",
                                         "medium",    "slow",      "slower",   "veryslow", "placebo", NULL};
@@ -327,6 +343,19 @@ x264_t *x264_encoder_open(x264_param_t *param) {
             pthread_mutex_destroy(&h->mtx);
             pthread_cond_destroy(&h->cv_work);
             pthread_cond_destroy(&h->cv_done);
+        } else {
+            /* helpers for the heavy steps: VENC_HOST_THREADS = packaging threads in all (default 3: the thread above + 2 helpers) */
+            int want = getenv("VENC_HOST_THREADS") ? atoi(getenv("VENC_HOST_THREADS")) - 2 : 2;
+            if (want > SHIM_MAX_HELPERS) want = SHIM_MAX_HELPERS;
+            if (want > h->gop_batch - 1) want = h->gop_batch - 1;
+            h->heavy_bytes = getenv("VENC_PACK_HEAVY_KB") ? (size_t)atol(getenv("VENC_PACK_HEAVY_KB")) << 10 : SHIM_HEAVY_STEP_BYTES;
+            pthread_mutex_init(&h->jmtx, NULL);
+            pthread_cond_init(&h->jcv_work, NULL);
+            pthread_cond_init(&h->jcv_done, NULL);
+            for (int i = 0; i < want; i++) {
+                if (pthread_create(&h->helper[h->n_helpers], NULL, packaging_helper, h) != 0) break;
+                h->n_helpers++;
+            }
         }
     }
     return h;
@@ -343,6 +372,15 @@ void x264_encoder_close(x264_t *h) {
         pthread_cond_broadcast(&h->cv_work);
         pthread_mutex_unlock(&h->mtx);
         pthread_join(h->worker, NULL);
+        pthread_mutex_lock(&h->jmtx);
+        h->j_stop = 1;
+        pthread_cond_broadcast(&h->jcv_work);
+        pthread_mutex_unlock(&h->jmtx);
+        for (int i = 0; i < h->n_helpers; i++) pthread_join(h->helper[i], NULL);
+        h->n_helpers = 0;
+        pthread_mutex_destroy(&h->jmtx);
+        pthread_cond_destroy(&h->jcv_work);
+        pthread_cond_destroy(&h->jcv_done);
         pthread_mutex_destroy(&h->mtx);
         pthread_cond_destroy(&h->cv_work);
         pthread_cond_destroy(&h->cv_done);
@@ -415,12 +453,13 @@ static int launch_pending(x264_t *h, int flush) {
 }
 
 /* wait for frame f on the GPU and package its slice RBSPs into NALs (host C, a4.6) */
-static int assemble_frame(x264_t *h, int64_t f) {
+static int assemble_frame_opt(x264_t *h, int64_t f, int step_done) {
     shim_frame *fr = &h->ring[f % h->pool];
     if (fr->assembled) return 0;
     /* the packaging thread only waits on tickets whose work has been flushed to the GPU (launch_pending ends every unit
-     * with venc_flush): venc_wait_issued touches no engine state */
-    if ((h->worker_on ? venc_wait_issued(h->ctx, fr->ticket) : venc_wait(h->ctx, fr->ticket)) != 0) return -1;
+     * with venc_flush): venc_wait_issued touches no engine state.  (step_done: the caller has waited for the frame's step and
+     * fetched its bytes.) */
+    if (!step_done && (h->worker_on ? venc_wait_issued(h->ctx, fr->ticket) : venc_wait(h->ctx, fr->ticket)) != 0) return -1;
     venc_frame vf;
     if (venc_get_frame(h->ctx, fr->out_slot, &vf) != 0) return -1;
     const size_t need = 256 + (size_t)vf.n_slices * 16 + (size_t)vf.total_bytes * 3 / 2;
@@ -465,6 +504,74 @@ static int assemble_frame(x264_t *h, int64_t f) {
     } else
         fr->assembled = 1;
     return 0;
+}
+
+static int assemble_frame(x264_t *h, int64_t f) { return assemble_frame_opt(h, f, 0); }
+
+/* a job's frames, taken one at a time by whoever is free (the packaging thread and its helpers) */
+static void pack_job_share(x264_t *h, int gen) {
+    for (;;) {
+        int64_t f = -1;
+        pthread_mutex_lock(&h->jmtx);
+        if (h->j_gen == gen && h->j_next < h->j_n) f = h->j_frames[h->j_next++];
+        pthread_mutex_unlock(&h->jmtx);
+        if (f < 0) return;
+        const int err = assemble_frame_opt(h, f, 1);
+        pthread_mutex_lock(&h->jmtx);
+        if (err) h->j_err = 1;
+        if (++h->j_done == h->j_n) pthread_cond_broadcast(&h->jcv_done);
+        pthread_mutex_unlock(&h->jmtx);
+    }
+}
+
+static void *packaging_helper(void *arg) {
+    x264_t *h = (x264_t *)arg;
+    (void)venc_bind_thread(h->ctx);
+    int seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&h->jmtx);
+        while (!h->j_stop && h->j_gen == seen) pthread_cond_wait(&h->jcv_work, &h->jmtx);
+        const int stop = h->j_stop;
+        seen = h->j_gen;
+        pthread_mutex_unlock(&h->jmtx);
+        if (stop) break;
+        pack_job_share(h, seen);
+    }
+    return NULL;
+}
+
+/* the frames base + g * keyint + t, g < gops, of a step that is complete and on the host: alone, or -- a heavy step -- with the helpers */
+static int assemble_step(x264_t *h, int64_t base, int t, int gops, int n) {
+    int64_t fs[64];
+    int cnt = 0;
+    for (int g = 0; g < gops && cnt < 64; g++) {
+        const int64_t k = (int64_t)g * h->keyint + t;
+        if (k < n) fs[cnt++] = base + k;
+    }
+    if (!cnt) return 0;
+    int heavy = 0;
+    if (h->worker_on && h->n_helpers > 0 && cnt >= 2) {
+        venc_frame vf;
+        const shim_frame *f0 = &h->ring[fs[0] % h->pool];
+        heavy = venc_get_frame(h->ctx, f0->out_slot, &vf) == 0 && (size_t)vf.total_bytes * (size_t)cnt >= h->heavy_bytes;
+    }
+    if (!heavy) {
+        for (int i = 0; i < cnt; i++)
+            if (assemble_frame_opt(h, fs[i], h->worker_on) != 0) return -1;
+        return 0;
+    }
+    pthread_mutex_lock(&h->jmtx);
+    memcpy(h->j_frames, fs, (size_t)cnt * sizeof(fs[0]));
+    h->j_n = cnt, h->j_next = 0, h->j_done = 0, h->j_err = 0;
+    const int gen = ++h->j_gen;
+    pthread_cond_broadcast(&h->jcv_work);
+    pthread_mutex_unlock(&h->jmtx);
+    pack_job_share(h, gen);
+    pthread_mutex_lock(&h->jmtx);
+    while (h->j_done < h->j_n) pthread_cond_wait(&h->jcv_done, &h->jmtx);
+    const int err = h->j_err;
+    pthread_mutex_unlock(&h->jmtx);
+    return err ? -1 : 0;
 }
 
 static int assemble_next_unit(x264_t *h);
@@ -530,10 +637,7 @@ static int assemble_next_unit(x264_t *h) {
                 if (venc_fetch(h->ctx, f0->out_slot, h->keyint, run) != 0) return -1;
                 if (run < cnt && venc_fetch(h->ctx, (int)((base + t + (int64_t)run * h->keyint) % h->pool), h->keyint, cnt - run) != 0) return -1;
             }
-            for (int g = 0; g < gops; g++) {
-                const int64_t k = (int64_t)g * h->keyint + t;
-                if (k < n && assemble_frame(h, base + k) != 0) return -1;
-            }
+            if (assemble_step(h, base, t, gops, n) != 0) return -1;
             if (h->trace_t0 > 0 && (t % 5 == 0 || t == h->keyint - 1))
                 fprintf(stderr, "venc trace:     step %d of unit at frame %lld packaged at +%.3f ms\n", t, (long long)base, now_ms() - h->trace_t0);
         }
