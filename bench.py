@@ -48,6 +48,7 @@ import ctypes as C
 import hashlib
 import importlib
 import json
+import math
 import os
 import sys
 import time
@@ -67,7 +68,7 @@ WORKLOADS = {
     "cif": dict(w=352, h=288, frames=300, keyint=30, qp=26, slices=8, name="CIF smoke workload"),
 }
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
-ME_EVENT_STRIDE = 8             # timed region: HIP-event pairs around every 8th k_me launch (each pair stalls the stream ~8 us: 1 in 4 cost 3.6 % of a 1080p pass)
+ME_EVENT_STRIDE = 7             # timed region: HIP-event pairs around every 7th k_me launch (each pair stalls the stream ~8 us: 1 in 4 cost 3.6 % of a 1080p pass).  Odd on purpose: the side chain works in batches of four steps, and one launch in eight always met the same phase of that cycle (rocprofv3 over all launches read 94 us where the sampled events read 100)
 ME_ALGO_BYTES_PER_PX = 2.0      # k_me reads cur Y (1.0) + ref Y (1.0) per P-frame pixel
 ORACLE_NOTE = "CPU oracle = this repo's own C restatement (oracle/), not libx264; parity with libx264 unpinned"
 
@@ -434,7 +435,10 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     # closed GOPs advanced in lock-step: the GOPs of one clip by default; with the in-loop filter or the Intra4x4 trial on -- kernels that
     # walk a dependency wavefront inside every slice, one block per (slice, item), and fill the chip only through the item count -- the
     # GOPs of three consecutive passes of the stream
-    gop_batch = args.gop_batch or ((frames + keyint - 1) // keyint) * (3 if (args.deblock or args.intra_modes >= 3) else 1)
+    # 0 = the encoder's own choice (x264_encoder_open: by picture size, include/x264.h; 30 at 1080p, 15 at 2160p, 32 with the wavefront tools);
+    # slices mode keeps one clip's GOPs per call (every call is one pass, and the exchange callback is per call)
+    n_gops = (frames + keyint - 1) // keyint
+    gop_batch = args.gop_batch or (n_gops if args.mode == "slices" else 0)
     fb = w * h * 3 // 2
     slices_mode = args.mode == "slices"
 
@@ -461,6 +465,9 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             band_kw = dict(slice_first=s0, slice_count=cnt, exchange=xc)
     enc = venc.X264Encoder(w, h, qp=wl["qp"], slices=wl["slices"], keyint=keyint, fps=(30, 1), sar=(1, 1),
                            gop_batch=gop_batch, device=local_rank, intra_modes=args.intra_modes, crf=args.crf, subpel=args.subpel, deblock=args.deblock, **band_kw)
+    gop_batch = enc.gop_batch()  # what 0 resolved to (after the cap by device memory)
+    # passes of the clip that make whole units: the untimed per-kernel passes below run this many, so that their launches hold as many items as the timed ones
+    unit_passes = 1 if slices_mode else (gop_batch // math.gcd(gop_batch, n_gops))
     if not args.no_profile:
         enc.profile(True, capacity=8 * frames * max(2, steps, warmup))
         # timed region: HIP-event pairs around the dominant kernel only (each pair stalls the stream for a
@@ -518,17 +525,18 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     if pipelined and tally is not None and int(tally.passes) >= 3:
         # the K passes are ONE pipelined stream: a pass "ends" when its last frame reaches the sink (CLOCK_MONOTONIC stamps
         # taken by the C tally sink); the first interval contains the pipeline's fill and is left out of the spread
-        ends = [int(tally.pass_end_ns[i]) for i in range(int(tally.passes))]
-        per = sorted((b - a) * 1e-9 for a, b in zip(ends[:-1], ends[1:]))
-        rate = lambda sec: round(frames * w * h / sec / 1e6, 1)
+        # (a unit of gop_batch GOPs delivers unit_passes passes at once: the intervals are taken between the ends of whole units)
+        ends = [int(tally.pass_end_ns[i]) for i in range(int(tally.passes))][unit_passes - 1::unit_passes]
+        per = sorted((b - a) * 1e-9 for a, b in zip(ends[:-1], ends[1:])) or [dt]
+        rate = lambda sec: round(unit_passes * frames * w * h / sec / 1e6, 1)
         spread = {"passes": len(per), "min": rate(per[-1]), "median": rate(per[len(per) // 2]), "max": rate(per[0]), "unit": "Mpixels/s",
-                  "what": "rate of each timed pass but the first, from the delivery time of its last frame to the sink (one pipelined stream: "
-                          "neighbouring passes overlap, so single passes can read above the whole-run value)"}
+                  "what": "rate of each timed unit (%d passes of the clip: the GOPs the encoder advances in lock-step) but the first, from the delivery time of its last frame to the sink "
+                          "(one pipelined stream: neighbouring units overlap, so single units can read above the whole-run value)" % unit_passes}
     bytes_per_step = int(tally.bytes) // (steps if pipelined else 1) if tally else None
     bytes_timed = int(tally.bytes) if tally else None
     prof, dropped = ({}, False) if args.no_profile else enc.profile_read()
     barrier()
-    if pipelined:
+    if pipelined and not args.no_check_pass:
         tally = one_pass()  # untimed: the digest of ONE pass, comparable across runs whatever --steps was
         if bytes_timed != steps * int(tally.bytes):  # every pass of the timed stream must have produced this pass's bytes
             raise SystemExit("bench: the %d timed passes produced %d bytes, %d x one pass = %d" % (
@@ -543,12 +551,15 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     if not args.no_profile and rank == 0:
         if not slices_mode or world == 1:  # (every rank would have to join the exchanges of an extra pass)
             enc.profile_select(None, stride=1)
-            enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+            enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=unit_passes)
             prof_all, _ = enc.profile_read()
             enc.set_overlap(False)
-            enc.encode_resident_tally(clip.data_ptr(), fb, frames)
+            enc.encode_resident_tally(clip.data_ptr(), fb, frames, repeats=unit_passes)
             prof_iso, _ = enc.profile_read()
             enc.set_overlap(True)
+            # per pass of the clip (the passes above were unit_passes long)
+            prof_all = {k: (v[0] / unit_passes, v[1]) for k, v in prof_all.items()}
+            prof_iso = {k: (v[0] / unit_passes, v[1]) for k, v in prof_iso.items()}
     barrier()
     digest, host = None, None
     if want_digest_frames and rank == 0 and not slices_mode:
@@ -602,9 +613,10 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
             me_ms, me_n = prof.get("k_me", (0.0, 0))
             if me_n:
                 # P launches of one pass over the clip: every unit of gop_batch GOPs advances keyint - 1 P pictures in lock-step
-                n_gops = (frames + keyint - 1) // keyint
-                launches_per_step = ((n_gops + gop_batch - 1) // gop_batch) * (keyint - 1)
-                px_per_launch = (frames - (frames + keyint - 1) // keyint) * w * h / launches_per_step
+                # (the timed stream holds steps x n_gops GOPs when the passes are pipelined into one stream, n_gops per call otherwise)
+                stream_gops = n_gops * (steps if pipelined else 1)
+                launches_per_stream = ((stream_gops + gop_batch - 1) // gop_batch) * (keyint - 1)
+                px_per_launch = stream_gops * (keyint - 1) * w * h / launches_per_stream
                 if slices_mode:  # rank 0 searches only its band
                     r0, r1 = venc.Engine.view(enc.L.x264_venc_engine(enc.h)).band_rows(*dmod.slice_band(wl["slices"], world, 0))
                     px_per_launch *= (r1 - r0) * 16.0 / h
@@ -653,16 +665,19 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
                     chain_ms = sum(prof_all.get(k, (0.0, 0))[0] for k in ("k_me", "k_me_fix", "k_inter"))
                     n_p = prof_all.get("k_me", (0.0, 0))[1]
                     if n_p:
-                        per = chain_ms / n_p * 1e-3
+                        per = chain_ms * unit_passes / n_p * 1e-3
                         res["roofline"]["p_path"] = {"algorithmic_bytes_per_step": int(1.5 * algo_bytes), "kernels": "k_me_pool + k_me_fix + chroma k_inter_fused",
                                                      "sum_of_kernel_us": round(per * 1e6, 2), "achieved": round(1.5 * algo_bytes / per / 1e9, 2),
                                                      "frac": round(1.5 * algo_bytes / per / 1e9 / HBM_PEAK_GBS, 5)}
                 iso_ms, iso_n = prof_iso.get("k_me", (0.0, 0))
                 if iso_n:
-                    iso_s = iso_ms / iso_n * 1e-3
+                    iso_s = iso_ms * unit_passes / iso_n * 1e-3  # (the milliseconds are per pass, the launch count is the run's)
+                    iso_px = unit_passes * n_gops * (keyint - 1) * w * h / iso_n
+                    iso_bytes = ME_ALGO_BYTES_PER_PX * iso_px
                     res["roofline"]["isolated_avg_launch_us"] = round(iso_s * 1e6, 2)
-                    res["roofline"]["isolated_achieved"] = round(algo_bytes / iso_s / 1e9, 2)
-                    res["roofline"]["isolated_frac"] = round(algo_bytes / iso_s / 1e9 / HBM_PEAK_GBS, 5)
+                    res["roofline"]["isolated_achieved"] = round(iso_bytes / iso_s / 1e9, 2)
+                    res["roofline"]["isolated_frac"] = round(iso_bytes / iso_s / 1e9 / HBM_PEAK_GBS, 5)
+                    res["roofline"]["isolated_algorithmic_bytes_per_launch"] = int(iso_bytes)
             if prof_all:  # untimed pass, both chains concurrent as in the timed region, event pairs around every kernel
                 res["kernel_ms_per_step"] = {k: round(v[0], 3) for k, v in prof_all.items()}
                 res["kernel_ms_per_step"]["sum"] = round(sum(v[0] for v in prof_all.values()), 3)
@@ -684,8 +699,10 @@ def measure(args, torch, dist, venc, wl_key, steps, warmup, rank, world, local_r
     extras = {}
     if rank == 0 and world == 1 and not slices_mode and args.pcie and wl_key == args.workload:
         extras["reference_defaults"] = reference_defaults(venc, torch, args.cpu_frames > 0, wl, clip, fb, local_rank)
-        extras["pcie_inclusive"] = pcie_inclusive(venc, torch, wl, clip, fb, gop_batch, local_rank)
-        extras["pcie_inclusive_rotating_pictures"] = pcie_inclusive(venc, torch, wl, clip, fb, gop_batch, local_rank, input_depth=2)
+        # (ten GOPs in lock-step, as in every earlier round: these legs are bound by the copy engine, more items only lengthen the fill and
+        # the drain of their 900-frame job; the encoder's own choice under the reference's call sequence is the reference_defaults leg)
+        extras["pcie_inclusive"] = pcie_inclusive(venc, torch, wl, clip, fb, n_gops, local_rank)
+        extras["pcie_inclusive_rotating_pictures"] = pcie_inclusive(venc, torch, wl, clip, fb, n_gops, local_rank, input_depth=2)
     del clip
     torch.cuda.empty_cache()
     return res, extras, host
@@ -697,7 +714,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30, help="timed passes over the clip (default 30: ~125 ms timed at 1080p; the pipeline's fill and drain, ~2.5 ms, are inside the timing)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="1080p", choices=sorted(WORKLOADS))
-    ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = all GOPs of the clip)")
+    ap.add_argument("--gop-batch", type=int, default=0, help="closed GOPs advanced in lock-step (0 = the encoder's choice: x264_encoder_open, include/x264.h)")
+    ap.add_argument("--no-check-pass", action="store_true", help="skip the untimed one-pass digest check behind the timed passes (counter runs: only whole units in the process)")
     ap.add_argument("--cpu-frames", type=int, default=300, help="frames of the all-cores CPU baseline sample, which is also the bit-exact check (0 = skip both); 300 = the whole clip, ~12 s on 16 cores")
     ap.add_argument("--no-extras", action="store_true", help="headline workload only: no 2160p object, no PCIe-inclusive leg (profiling runs)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")

@@ -97,11 +97,13 @@ typedef struct x264_param_t {
     struct {                /* engine extension, not part of libx264 */
         int i_device;       /* HIP device ordinal */
         /* Closed GOPs encoded in lock-step ("items"): 1 = frame-by-frame streaming; 0 (x264_param_default_preset; tune zerolatency:
-         * 1) = chosen by x264_encoder_open: 10, or with the in-loop filter or the Intra4x4 trial on -- whose kernels launch one block
-         * per slice and item -- enough that items x slices reaches the chip's 256 CUs (32 with the default 8 slices).
+         * 1) = chosen by x264_encoder_open: about 245 000 macroblocks per step and never fewer than 15 items (30 at 1080p, 15 at
+         * 2160p: what fills the chip best, measured), or with the in-loop filter or the Intra4x4 trial on -- whose kernels launch one
+         * block per slice and item -- at least enough that items x slices reaches the chip's 256 CUs (32 with the default 8 slices).
          * WHAT IT COSTS THE CALLER.  Delay: x264_encoder_encode returns 0 (av_encode.c:971-974) for the first 1.5 x i_gop_batch x
-         * i_keyint_max pictures (450 / 1440 with the defaults: a unit is launched when its last picture is in, and half a unit of further
-         * pictures covers its time on the GPU) and the rest arrives through the x264_encoder_delayed_frames loop (:1076-1083).
+         * i_keyint_max pictures (1350 / 1440 at 1080p with a key-frame interval of 30: a unit is launched when its last picture is in, and
+         * half a unit of further pictures covers its time on the GPU) and the rest arrives through the x264_encoder_delayed_frames loop
+         * (:1076-1083).  A caller that wants its first frame earlier sets i_gop_batch itself (10 items: 450 pictures, 12 % slower).
          * Memory: the encoder pools twice that many pictures in HBM -- per picture its I420 input (1.5 B/px) and an output slot of
          * 400 bytes per macroblock (the conformance bound), 6.4 MB at 1080p, 25.4 MB at 2160p -- plus ~22 KB per macroblock and item
          * of working buffers: 3.9 / 12.3 GB at 1080p with 10 / 32 items, 15.5 / 49 GB at 2160p.  Whatever is asked for here or chosen,

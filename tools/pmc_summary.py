@@ -41,7 +41,8 @@ if me + "_hbm_read_bytes_per_launch" in out:
 path = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
 doc = json.load(open(path)) if os.path.exists(path) else {}
 doc["note"] = ("HBM bytes per launch from rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of bench.py "
-               "--steps 1 --warmup 0 --no-profile, 10 items per launch; tools/pmc_summary.py). FETCH_SIZE and WRITE_SIZE are in KiB; "
+               "--steps 3 --warmup 0 --no-profile --no-check-pass: whole units only, the encoder's own item count per launch (30 at 1080p, 15 at 2160p); "
+               "tools/pmc_summary.py). FETCH_SIZE and WRITE_SIZE are in KiB; "
                "FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (128-B requests tallied at 64 B).")
 doc[sys.argv[3]] = out
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

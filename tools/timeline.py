@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-step timeline of one steady-state pass from a rocprofv3 --kernel-trace CSV:
+"""Per-step timeline of one steady-state unit (the encoder's GOPs in lock-step: 30 at 1080p = three passes of the clip) from a rocprofv3 --kernel-trace CSV:
 usage: python tools/timeline.py <dir> [n_steps_to_print]
 Prints, for the last full pass in the trace, every kernel of the first steps with start (us since the pass began),
 duration and the gap to the previous kernel on the same queue, then per-kernel totals and the main-chain period."""
@@ -13,12 +13,12 @@ for r in rows:
 rows.sort(key=lambda r: r['s'])
 idx = [i for i, r in enumerate(rows) if r['n'].startswith('k_intra_fwd')]
 if len(idx) < 3:
-    raise SystemExit("need at least three passes in the trace")
+    raise SystemExit("need at least three units in the trace")
 mid = len(idx) // 2
 a, b = idx[mid], idx[mid + 1]    # a pass from the middle of the run (steady state): from its k_intra_fwd to the next one
 seg = rows[a:b]
 t0 = seg[0]['s']
-print("pass span %.1f us, %d kernels" % ((rows[b]['s'] - t0) / 1e3, len(seg)))
+print("unit span %.1f us, %d kernels" % ((rows[b]['s'] - t0) / 1e3, len(seg)))
 last_end = {}
 me_starts = [r['s'] for r in seg if r['n'].startswith('k_me_pool')]
 lim = me_starts[nshow] if len(me_starts) > nshow else seg[-1]['e']

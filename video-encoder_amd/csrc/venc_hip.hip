@@ -194,7 +194,7 @@ struct venc_ctx {
     int intra_waves;
     int last_batch_p; /* the last entropy batch coded P pictures (venc_debug_read derives their per-macroblock bits from the entries) */
     venc_step last_batch_S;
-    int me_xcd;       /* XCD-aware tile order of the search (VENC_ME_XCD; default from 200 000 macroblocks per step, see venc_open) */
+    int me_xcd;       /* XCD-aware tile order of the search (VENC_ME_XCD; default for pictures beyond 1080p from 200 000 macroblocks per step, see venc_open) */
     int intra_cw;     /* compute waves of k_intra_dc (the other waves of its 16 stage the records) */
     int intra_legacy; /* VENC_INTRA=legacy: the one-kernel wavefront k_intra */
     int max_slice_mbs;
@@ -568,7 +568,10 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
          * steps (streaming engines) stay unmasked.  VENC_ENTROPY_CUS=0 / =n overrides. */
         const char *e = getenv("VENC_ENTROPY_CUS");
         const long long step_mbs = (long long)g.nmb * cfg->max_items;
-        const int ncu = e ? atoi(e) : step_mbs >= 200000 ? 160 : step_mbs >= 60000 ? 192 : 0;
+        /* Third session of round 4 (gpurun_out/r04_s3g ... r04_s3i; the search 5 % shorter, the host's packaging no longer in the way): 1080p x 10
+         * items 185.9 on 224, 187.5 on 192, 191.0 on 160; x 24 items 193.4 on 96, 214.6 on 128, 213.1 on 160, 209.4 on 192; 2160p x 12 items
+         * 238.6 on 96, 249.5 on 128, 248.4 on 160: 160 CUs from 60 000 macroblocks per step, 128 from 150 000. */
+        const int ncu = e ? atoi(e) : step_mbs >= 150000 ? 128 : step_mbs >= 60000 ? 160 : 0;
         hipDeviceProp_t prop;
         OPEN_OK(hipGetDeviceProperties(&prop, cfg->device));
         c->lds_per_block = prop.sharedMemPerBlock;
@@ -768,7 +771,8 @@ extern "C" int venc_open(const venc_config *cfg, venc_ctx **out) {
     /* XCD-aware tile order of the search (runs of 64 tiles dealt to the eight XCDs in rotation: a tile's neighbours share an L2).  Default from
      * 200 000 macroblocks per step (2160p x 10 items: 223.4 - 225.6 -> 228.3 - 231.6 Gpx/s in three same-box A/Bs of round 4; at 1080p x 10 the
      * launch gets 5 - 8 % longer and the pass does not change); whole pictures only (a band's search may go as two launches) */
-    c->me_xcd = getenv("VENC_ME_XCD") ? atoi(getenv("VENC_ME_XCD")) != 0 : (long long)g.nmb * cfg->max_items >= 200000;
+    /* (by the PICTURE's size as well as the step's: 1080p x 20 items 207.6 Gpx/s in raster order, 195.6 in XCD order; 2160p x 10 items 240.5 / 244.3) */
+    c->me_xcd = getenv("VENC_ME_XCD") ? atoi(getenv("VENC_ME_XCD")) != 0 : g.nmb >= 20000 && (long long)g.nmb * cfg->max_items >= 200000;
     c->inter_legacy = getenv("VENC_INTER") && !strcmp(getenv("VENC_INTER"), "legacy");
     if (cfg->deblock && (c->me_mode != 0 || c->inter_legacy || (getenv("VENC_INTRA") && !strcmp(getenv("VENC_INTRA"), "legacy")))) {
         SET_ERR("venc_open: the in-loop filter runs behind the shipped kernels only (VENC_ME / VENC_INTER / VENC_INTRA select test kernels)");

@@ -199,11 +199,18 @@ void x264_picture_clean(x264_picture_t *pic) {
  * the search and the transforms launch items x macroblocks-per-picture lanes -- ten 1080p pictures are 5100 search blocks on 1024
  * block slots --, but the WAVEFRONT tools (in-loop filter, Intra4x4 trial) launch one block per slice and item and take as long
  * for 80 blocks as for 256: with either on, items x slices should reach the chip's 256 CUs. */
+/* ... and how many items fill it best depends on the picture (same box, resident 1080p clip, side chain on 128 CUs: 10 items 188 Gpx/s,
+ * 16: 204, 24: 215, 28: 218, 32: 218; 2160p: 6 items 226, 8: 241, 10: 241, 12: 249, 14: 252, 16: 251, 20: 218 -- gpurun_out/r04_s3h, r04_s3i):
+ * launches, the waits between the chains and the host's per-step work are paid per step, whatever it holds.  About 245 000 macroblocks
+ * per step, never fewer than 15 items: 30 at 1080p, 15 at 2160p.  The price is delay (a unit and a half: 1350 pictures at 1080p) and
+ * pool memory (include/x264.h), both capped below by what the device holds. */
 static int shim_auto_gop_batch(const x264_param_t *p, int n_slices) {
-    int g = 10;
+    const long nmb = (long)((p->i_width + 15) / 16) * (long)((p->i_height + 15) / 16);
+    int g = (int)(244800 / (nmb > 0 ? nmb : 1));
+    if (g < 15) g = 15;
     if (p->hip.i_deblock || p->hip.i_intra_modes >= 3) {
-        g = (256 + n_slices - 1) / n_slices;
-        if (g < 10) g = 10;
+        const int gw = (256 + n_slices - 1) / n_slices;
+        if (g < gw) g = gw;
     }
     return g > VENC_MAX_ITEMS ? VENC_MAX_ITEMS : g;
 }
