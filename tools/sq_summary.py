@@ -4,7 +4,7 @@ usage: sq_summary.py <dir with SQ_INSTS_VALU/ SQ_BUSY_CYCLES/ SQ_LDS_BANK_CONFLI
 Collect with (on the GPU box, cd /tmp; export TMPDIR=/tmp):
   for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \\
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM"; do
-    VENC_NO_OVERLAP=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${c%% *} -- python3 bench.py --workload W --steps 1 --warmup 0 --cpu-frames 0 --no-profile
+    VENC_NO_OVERLAP=1 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${c%% *} -- python3 bench.py --workload W --steps 3 --warmup 0 --cpu-frames 0 --no-profile --no-check-pass
   done"""
 import collections
 import csv
@@ -26,8 +26,8 @@ for sub in ("SQ_INSTS_VALU", "SQ_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT"):
         if sub == "SQ_INSTS_VALU" and r["Counter_Name"] == "SQ_INSTS_VALU":
             dur[k][0] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             dur[k][1] += 1
-print("# rocprofv3 --pmc (three separate passes, --kernel-trace only) of: VENC_NO_OVERLAP=1 python3 bench.py --steps 1 --warmup 0 --cpu-frames 0 --no-profile")
-print("# %s, 10 items per launch, every kernel alone on the chip (one stream).  Counter values are sums over all shader engines, averaged per launch." % label)
+print("# rocprofv3 --pmc (three separate passes, --kernel-trace only) of: VENC_NO_OVERLAP=1 python3 bench.py --steps 3 --warmup 0 --cpu-frames 0 --no-profile --no-check-pass")
+print("# %s, whole units of the encoder's own item count per launch (30 at 1080p, 15 at 2160p), every kernel alone on the chip (one stream).  Counter values are sums over all shader engines, averaged per launch." % label)
 print("# valu_util = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x duration x 2.4 GHz); lds_busy = SQ_LDS_IDX_ACTIVE / (256 CUs x duration x 2.4 GHz)")
 names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_BUSY_CYCLES",
          "SQ_WAVE_CYCLES", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAIT_INST_LDS"]
@@ -53,7 +53,7 @@ if len(sys.argv) > 3:  # sq_summary.py <dir> <label> <profiles/sq_counters.json>
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     path = sys.argv[3]
     doc = json.load(open(path)) if os.path.exists(path) else {}
-    doc["note"] = ("per launch, every kernel alone on the chip (VENC_NO_OVERLAP=1), 10 items per launch; valu_issue_frac = SQ_INSTS_VALU x %.1f cycles "
+    doc["note"] = ("per launch, every kernel alone on the chip (VENC_NO_OVERLAP=1), the encoder's own item count per launch (30 at 1080p, 15 at 2160p); valu_issue_frac = SQ_INSTS_VALU x %.1f cycles "
                    "(measured issue cost of a wave-instruction, tools/valu_ubench.hip) / (1024 SIMDs x duration x 2.4 GHz)" % VALU_ISSUE_CYCLES)
     doc[label] = doc_k
     doc["source"] = {"kernel_sources_sha16": importlib.import_module("video-encoder_amd").kernel_sources_sha16(), "collected": time.strftime("%Y-%m-%d"),
