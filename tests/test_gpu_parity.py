@@ -333,6 +333,8 @@ def test_intra_three_kernels_equal_the_wavefront_kernel(venc, legacy_lib, w, h, 
     {"VENC_CHAINS": "2"},               # round 4: the items of a P step as two search -> fix chains on two streams
     {"VENC_CHAINS": "2", "VENC_INTRA_AHEAD": "0"},   # ... with intra steps on the main stream (the chains resynchronise around them)
     {"VENC_PRIO": "1"},                 # main chain at the highest stream priority, side chain at the lowest
+    {"VENC_HOST_THREADS": "2"},         # packaging thread without helpers
+    {"VENC_PACK_HEAVY_KB": "1"},        # every step's frames shared between the packaging thread and its helper
 ])
 def test_launcher_variants_change_nothing(venc, orc, monkeypatch, env):
     """Every scheduling variant of the launcher -- where the transforms run, how many steps an entropy
