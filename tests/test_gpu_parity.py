@@ -890,6 +890,22 @@ def test_reference_open_sequence_at_1080p_chooses_its_items_and_matches_oracle(v
         assert got[t].payload == enc.encode(*f).data, "frame %d" % t
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,want", [(1920, 1080, 30), (3840, 2160, 15), (2560, 1440, 17), (1280, 720, 64), (352, 288, 64)])
+def test_items_in_lock_step_follow_the_picture_size(venc, w, h, want):
+    """hip.i_gop_batch = 0 without the wavefront tools (the configuration bench.py quotes): about 245 000 macroblocks per step, at
+    least 15 items, at most the engine's 64 (x264_shim.c shim_auto_gop_batch; include/x264.h: delay and memory); with them at least
+    256 / slices.  Nothing is encoded: open, ask, close."""
+    e = venc.X264Encoder(w, h, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(1, 1), gop_batch=0)
+    got = e.gop_batch()
+    e.close()
+    assert got == want
+    e = venc.X264Encoder(w, h, qp=26, slices=8, keyint=30, fps=(30, 1), sar=(1, 1), gop_batch=0, deblock=True)
+    got = e.gop_batch()
+    e.close()
+    assert got == max(want, 32)
+
+
 def test_long_key_frame_interval_is_capped_by_device_memory_not_a_failed_open(venc, monkeypatch):
     """the unit is gop_batch x keyint frames and the pools twice that; with libx264's own default interval of 250
     at 2160p the preset's 32 items would ask for 400 GB.  x264_encoder_open lowers the items until the pools fit half of the free
