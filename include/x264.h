@@ -106,10 +106,11 @@ typedef struct x264_param_t {
          * (:1076-1083).  A caller that wants its first frame earlier sets i_gop_batch itself (10 items: 450 pictures, 12 % slower).
          * Memory: the encoder pools twice that many pictures in HBM -- per picture its I420 input (1.5 B/px) and an output slot of
          * 400 bytes per macroblock (the conformance bound), 6.4 MB at 1080p, 25.4 MB at 2160p -- plus ~22 KB per macroblock and item
-         * of working buffers: 3.9 / 12.3 GB at 1080p with 10 / 32 items, 15.5 / 49 GB at 2160p.  Whatever is asked for here or chosen,
+         * of working buffers: 3.9 / 11.5 / 12.3 GB at 1080p with 10 / 30 / 32 items, 15.5 / 23 / 49 GB at 2160p with 10 / 15 / 32.  Whatever is asked for here or chosen,
          * x264_encoder_open lowers it until that fits into half of the device's free memory (a long i_keyint_max -- libx264's own
-         * default is 250 -- ends with fewer items, never with a failed open).  Host memory: 40 + pinned output buffers of that slot
-         * size whatever the pool (130 MB at 1080p), and the packaged NAL payloads of the pooled pictures (their real size). */
+         * default is 250 -- ends with fewer items, never with a failed open).  Host memory: four steps' worth of pinned
+         * output buffers of that slot size (4 x items, at least 8: 390 MB at 1080p with 30 items) whatever the pool, and the packaged NAL
+         * payloads of the pooled pictures (their real size). */
         int i_gop_batch;
         int i_gop_base;     /* index of this encoder's first GOP in the whole stream (GOP-sharded multi-GPU runs) */
         /* slice-parallel multi-GPU mode (BASELINE config 5): this encoder codes only
